@@ -1,0 +1,143 @@
+"""Pin the CPU oracle (oracle/titok_oracle.py) against fixtures generated from the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import titok_oracle as O
+from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fsq_kat(tag):
+    d = load("fsq_kat.npz")
+    levels = d[f"levels_{tag}"].tolist()
+    z = torch.from_numpy(d[f"z_{tag}"])
+    codes, idx, bounded = O.fsq_forward(z, levels)
+    assert np.array_equal(idx.numpy(), d[f"indices_{tag}"])           # bit-exact integer indices
+    assert np.array_equal(codes.numpy(), d[f"codes_{tag}"])
+    assert np.array_equal(bounded.numpy(), d[f"bounded_{tag}"])
+    n = int(np.prod(levels))
+    cb = O.fsq_indices_to_codes(torch.arange(n, dtype=torch.int32), levels)
+    assert np.array_equal(cb.numpy(), d[f"codebook_{tag}"])
+    # round trip + range
+    _, idx2, _ = O.fsq_forward(torch.atanh(cb.clamp(-0.999, 0.999)) * 0 + cb * 10, levels)
+    assert idx.min() >= 0 and idx.max() < n
+
+
+def test_fsq_is_lattice_argmin_away_from_ties():
+    levels = [7, 5, 5, 5, 5]
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2000, 5, generator=g) * 1.5
+    codes, idx, bounded = O.fsq_forward(z, levels)
+    n = int(np.prod(levels))
+    lattice = O.fsq_indices_to_codes(torch.arange(n, dtype=torch.int32), levels) * (torch.tensor(levels) // 2)
+    arg = torch.cdist(bounded, lattice.float()).argmin(-1).to(torch.int32)
+    keep = O.fsq_margin(bounded) > 1e-4
+    assert torch.equal(arg[keep], idx[keep])
+
+
+def test_rope_table_and_rotary():
+    d = load("rope_kat.npz")
+    for i in range(4):
+        cos, sin = O.rope_table(d[f"grids_{i}"].tolist(), d[f"counts_{i}"].tolist())
+        assert np.array_equal(cos.numpy(), d[f"cos_{i}"])
+        assert np.array_equal(sin.numpy(), d[f"sin_{i}"])
+    cos, sin = O.rope_table(d["grids_1"].tolist(), d["counts_1"].tolist())
+    out = O.apply_rotary(torch.from_numpy(d["rot_q"]), cos, sin)
+    np.testing.assert_allclose(out.numpy(), d["rot_out"], rtol=0, atol=1e-6)
+    # RoPE leaves the last 4 dims of each head untouched (rope.py:24,40)
+    assert np.array_equal(out.numpy()[..., 60:], d["rot_q"][..., 60:])
+
+
+def test_patchify_roundtrip():
+    d = load("patch_kat.npz")
+    clip = torch.from_numpy(d["clip"])
+    p = O.patchify(clip, (4, 8, 8))
+    assert np.array_equal(p.numpy(), d["patches"])
+    assert torch.equal(O.unpatchify(p, (2, 2, 3), (4, 8, 8), 3), clip)
+
+
+def test_codebook_scores():
+    d = load("codebook_kat.npz")
+    sizes = d["sizes"].tolist()
+    samples = list(torch.split(torch.from_numpy(d["flat"]), sizes))
+    n = int(d["codebook_size"])
+    usage, ent, _ = O.codebook_scores(samples[-n:], n)     # FIFO keeps the last `codebook_size` samples
+    assert abs(usage - float(d["usage"])) < 1e-4
+    assert abs(ent - float(d["entropy"])) < 1e-5
+
+
+def test_blocks_kat():
+    d = load("blocks_kat.npz")
+    sd = seeded_titok_state(int(d["weight_seed"]))
+    grids, counts = d["grids"].tolist(), d["counts"].tolist()
+    cu = [0]
+    for g, k in zip(grids, counts):
+        cu.append(cu[-1] + int(np.prod(g)) + k)
+    cos, sin = O.rope_table(grids, counts)
+    x = torch.from_numpy(d["x"])
+    a1 = O.attn_sublayer(x, sd, "encoder.model_layers.attn_layer.1.", (4, 2), cos, sin, cu)
+    f1 = O.geglu_sublayer(x, sd, "encoder.model_layers.ffd_layer.1.")
+    st = O.transformer_stack(x, sd, "encoder.model_layers.", 4, (4, 2), cos, sin, cu)
+    np.testing.assert_allclose(a1.numpy(), d["attn1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(f1.numpy(), d["ffd1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(st.numpy(), d["stack"], rtol=1e-4, atol=1e-4)
+
+
+def _run_small(name):
+    d = load(name)
+    sd = seeded_titok_state(int(d["weight_seed"]))
+    if "shapes" in d:
+        shapes, counts = d["shapes"].tolist(), d["counts"].tolist()
+    else:
+        shapes, counts = [d["shape"].tolist()], [int(d["count"])]
+    clips = synthetic_clips(shapes, seed=int(d["clip_seed"]))
+    with torch.no_grad():
+        recon, idx, z, bounded = O.titok_forward(clips, counts, sd, [7, 5, 5, 5, 5])
+    return d, recon, idx, z, bounded
+
+
+def test_titok_small_matches_reference():
+    d, recon, idx, z, bounded = _run_small("titok_small.npz")
+    assert np.array_equal(idx.numpy(), d["indices"])                       # token indices bit-exact
+    np.testing.assert_allclose(z.numpy(), d["z"], rtol=1e-4, atol=1e-4)
+    for i, r in enumerate(recon):
+        np.testing.assert_allclose(r.numpy(), d[f"recon_{i}"], rtol=1e-3, atol=1e-3)
+
+
+def test_packing_invariance_and_single():
+    d, recon, idx, z, bounded = _run_small("titok_single.npz")
+    assert np.array_equal(idx.numpy(), d["indices"])
+    np.testing.assert_allclose(recon[0].numpy(), d["recon"], rtol=1e-3, atol=1e-3)
+
+
+def test_titok_cfg1_matches_reference():
+    """BASELINE config #1: 4 x 16x128x128 clips, K=128, tiny, fp32 CPU."""
+    d, recon, idx, z, bounded = _run_small("titok_cfg1.npz")
+    ref_idx = d["indices"]
+    margin = O.fsq_margin(torch.from_numpy(d["bounded"]))
+    safe = (margin > 1e-3).numpy()
+    assert np.array_equal(idx.numpy()[safe], ref_idx[safe])
+    assert (idx.numpy() == ref_idx).mean() > 0.995
+    rs = torch.stack(recon)[:, :, ::4, ::8, ::8]
+    np.testing.assert_allclose(rs.numpy(), d["recon_sample"], rtol=2e-3, atol=2e-3)
+
+
+def test_decode_indices_equals_decode():
+    d = load("titok_small.npz")
+    sd = seeded_titok_state(0)
+    shapes, counts = d["shapes"].tolist(), d["counts"].tolist()
+    codes = torch.from_numpy(d["codes"])
+    a = O.titok_decode(codes, counts, shapes, sd)
+    b = O.titok_decode_indices(torch.from_numpy(d["indices"]), shapes, counts, sd, [7, 5, 5, 5, 5])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
