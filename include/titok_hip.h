@@ -1,0 +1,203 @@
+/* titok_hip.h - C-ABI of libtitok_hip.so: the MI355X (gfx950) compute path of the TiTok-Video tokenizer.
+ *
+ * The reference (NilanEkanayake/TiTok-Video) exposes this path as a Python nn.Module API, not an FFI
+ * (SURVEY.md section 8b).  The Python mirror in titok_video_amd/model/ keeps that API and binds these
+ * entry points with ctypes; every entry point below names the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, floats, an opaque hipStream_t passed as void*.  No torch types.
+ *   - every call only ENQUEUES work on `stream` and never synchronises; no hidden global state, no allocation:
+ *     the caller owns all buffers including the workspace (size from ttv_tower_workspace_bytes).
+ *   - return value: 0 = TTV_OK, otherwise a TTV_ERR_* code; ttv_error_string() explains the last error of
+ *     the calling thread.  The Python shim raises RuntimeError on any non-zero code.
+ *   - activations/weights of linear layers are in the compute dtype (TTV_BF16 or TTV_F32); RMSNorm gains,
+ *     mask_token, rope tables and all statistics are fp32; matrix products accumulate in fp32.
+ *   - rows of a packed batch: for clip b, rows [cu[b], cu[b]+K_b) are its latent tokens, rows
+ *     [cu[b]+K_b, cu[b+1]) its patch tokens in (t,h,w) raster order (model/base/blocks.py:85-86).
+ */
+#ifndef TITOK_HIP_H
+#define TITOK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTV_OK 0
+#define TTV_ERR_INVALID 1      /* bad argument / unsupported shape */
+#define TTV_ERR_LAUNCH 2       /* hip launch error */
+#define TTV_ERR_UNSUPPORTED 3
+
+#define TTV_BF16 0
+#define TTV_F32 1
+
+#define TTV_ENCODER 0
+#define TTV_DECODER 1
+
+#define TTV_MAX_FSQ 8
+#define TTV_MAX_CLIPS_PER_LAUNCH 64
+
+const char* ttv_error_string(void);
+int ttv_version(void);
+
+/* ---- FSQ (model/quantizer/fsq.py) -------------------------------------------------------------------- */
+typedef struct ttv_fsq_params {
+  int32_t n;                        /* codebook_dim = len(levels)                         fsq.py:69 */
+  int32_t levels[TTV_MAX_FSQ];      /* _levels                                            fsq.py:63 */
+  int32_t basis[TTV_MAX_FSQ];       /* _basis = cumprod([1]+levels[:-1])                  fsq.py:66 */
+  float half_l[TTV_MAX_FSQ];        /* (levels-1)*(1+eps)/2, fp32, computed by the host   fsq.py:80 */
+  float offset[TTV_MAX_FSQ];        /* 0.5 for even levels                                fsq.py:81 */
+  float shift[TTV_MAX_FSQ];         /* atanh(offset/half_l)                               fsq.py:82 */
+  float half_width[TTV_MAX_FSQ];    /* levels // 2                                        fsq.py:89 */
+} ttv_fsq_params;
+
+/* FSQ.forward (fsq.py:123-135): z [rows,n] (dtype) -> codes [rows,n] (dtype), indices int32 [rows];
+ * bounded (fp32 [rows,n], value before rounding) is optional (NULL to skip). */
+int ttv_fsq_forward(const ttv_fsq_params* p, const void* z, int z_dtype, int rows, void* codes, int codes_dtype,
+                    int32_t* indices, float* bounded, void* stream);
+/* FSQ.indices_to_codes (fsq.py:100-121): int32 [rows] -> codes [rows,n] (dtype). */
+int ttv_fsq_indices_to_codes(const ttv_fsq_params* p, const int32_t* indices, int rows, void* codes, int codes_dtype,
+                             void* stream);
+
+/* ---- single ops (exported for parity tests; the tower entry points below chain them) ------------------ */
+
+/* RMSNorm (flash_attn RMSNorm as used at blocks.py:51-52,66 / transformer.py:42,77,122-123):
+ * out[dst_rows[i]] = in[src_rows[i]] * rsqrt(mean(in^2)+eps) * gain, fp32 math.  Row maps may be NULL (identity). */
+int ttv_rmsnorm(const void* in, int in_dtype, int ld_in, const int32_t* src_rows, void* out, int out_dtype, int ld_out,
+                const int32_t* dst_rows, const float* gain, int rows, int width, float eps, void* stream);
+
+/* apply_rotary_emb (model/base/rope.py:19-27) on x [rows, heads, 64] in place; rope_cs fp32 [rows,64] =
+ * (cos[32] | sin[32]) per row, entries 30,31 = (1,0) so the last 4 dims of a head stay untouched. */
+int ttv_rope_apply(void* x, int dtype, int ld, int rows, int heads, const float* rope_cs, void* stream);
+
+/* y[M,N] = x[M,K] @ w[N,K]^T (+ bias[N]) (+ *add_scalar): nn.Linear (blocks.py:93,166,173; transformer.py:49,55,87,104). */
+int ttv_linear(const void* x, int ldx, const void* w, int ldw, const void* bias, const float* add_scalar, void* y, int ldy,
+               int M, int N, int K, int dtype, void* stream);
+
+/* to_qkv + rotary (transformer.py:87,97-98): y[M, 2d+2g] = x @ w^T with apply_rotary_emb fused on the q columns
+ * [0,d) and k columns [2d,2d+g); rope_cs as in ttv_rope_apply. */
+int ttv_linear_qkv_rope(const void* x, int ldx, const void* w, int ldw, void* y, int ldy, int M, int d_model, int gqa_dim,
+                        const float* rope_cs, int dtype, void* stream);
+/* GEGLU w12 + activation (transformer.py:49-52): w [2I,K]; y[M,I] = gelu_erf(x@w[I:]^T) * (x@w[:I]^T). */
+int ttv_linear_geglu(const void* x, int ldx, const void* w, int ldw, void* y, int ldy, int M, int I, int K, int dtype,
+                     void* stream);
+/* out_proj / w3 + residual (transformer.py:129-130,141,144): y = alpha*resid + x@w^T; y is fp32 when y_f32 != 0
+ * (the KEEL pre-norm sum), else dtype (in-place on resid allowed). */
+int ttv_linear_residual(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha, void* y,
+                        int ldy, int y_f32, int M, int N, int K, int dtype, void* stream);
+
+/* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
+ * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
+ * Non-causal, block-diagonal over cu_seqlens (device int32 [n_seq+1]), GQA, softmax scale head_dim^-0.5.
+ * qblocks: device int32 [n_qblocks,2] = (sequence id, first query row within the sequence), 128 rows per block.
+ * If gate_mul == 0 the raw attention output is written. */
+int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
+                  int n_qblocks, int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream);
+
+/* patch_rearrange (model/base/utils.py:26-34) for up to TTV_MAX_CLIPS_PER_LAUNCH clips per call.
+ * clips: HOST array of device pointers [n_clips] to [C,T,H,W] tensors; clip_desc: DEVICE int32 [n_clips,8] =
+ * (T,H,W, gt,gh,gw, first patch row, C).  Output rows hold the patch vector in (c,pt,ph,pw) order - the
+ * reference's (pt,ph,pw,c) order is folded into the packed proj_in / proj_out weight (see weights.py). */
+int ttv_patch_gather(const void* const* clips, const int32_t* clip_desc, int clip0, int n_clips, int patch_t, int patch_h,
+                     int patch_w, int channels, void* patches, int ld, int dtype, int max_patches_per_clip, void* stream);
+/* unpatch_rearrange (model/base/utils.py:37-51); same descriptors, clips are written. */
+int ttv_patch_scatter(const void* patches, int ld, const int32_t* clip_desc, int clip0, int n_clips, int patch_t, int patch_h,
+                      int patch_w, int channels, void* const* clips, int dtype, int max_patches_per_clip, void* stream);
+
+/* ---- towers (model/base/blocks.py TiTokEncoder 31-104 / TiTokDecoder 108-177) ------------------------- */
+typedef struct ttv_tower_dims {
+  int32_t kind;          /* TTV_ENCODER / TTV_DECODER */
+  int32_t dtype;         /* compute dtype */
+  int32_t width;         /* d                                   utils.py:22 */
+  int32_t layers;        /*                                     utils.py:9-14 */
+  int32_t q_heads, kv_heads, head_dim;   /*                     utils.py:15-20, transformer.py:73-75 */
+  int32_t inner;         /* GEGLU hidden I                      transformer.py:39-40 */
+  int32_t patch_t, patch_h, patch_w;
+  int32_t pix_channels;  /* 3 */
+  int32_t token_size;    /* len(fsq_levels) (encoder out / decoder in); 1 for the discriminator use */
+  float eps;             /* RMSNorm eps 1e-5 */
+  float alpha;           /* KEEL residual scale 2*layers        transformer.py:117 */
+} ttv_tower_dims;
+
+typedef struct ttv_layer_weights {
+  const float* pre_ln;        /* attn_layer.i.pre_ln.weight [d]            */
+  const void* to_qkv;         /* attn_layer.i.to_qkv.weight [2d+2g, d]     */
+  const void* out_proj;       /* attn_layer.i.out_proj.weight [d, d]       */
+  const float* ffd_norm;      /* ffd_layer.i.norm.weight [d]               */
+  const void* w12;            /* ffd_layer.i.w12.weight [2I, d]            */
+  const void* w3;             /* ffd_layer.i.w3.weight [d, I]              */
+  const float* attn_post_ln;  /* attn_post_ln.(i-1).weight, NULL for i==0  */
+  const float* ffd_post_ln;   /* ffd_post_ln.(i-1).weight, NULL for i==0   */
+} ttv_layer_weights;
+
+typedef struct ttv_tower_weights {
+  const void* proj_in_w;      /* enc: [d, C*pt*ph*pw] columns in (c,pt,ph,pw) order; dec: [d, token_size] */
+  const void* proj_in_b;      /* [d] */
+  const float* mask_token;    /* [1] */
+  const float* ln_pre_t;      /* [d] */
+  const float* ln_pre_p;      /* [d] */
+  const float* ln_post;       /* [d] */
+  const void* proj_out_w;     /* enc: [token_size, d]; dec: [C*pt*ph*pw, d] rows in (c,pt,ph,pw) order */
+  const void* proj_out_b;     /* enc: [token_size]; dec: [C*pt*ph*pw] same order */
+  const ttv_layer_weights* layers;   /* HOST array [layers] */
+} ttv_tower_weights;
+
+/* Per-batch metadata, built on the host from Python ints (replaces the device-side bookkeeping and its
+ * host syncs at blocks.py:80-88 / 154-162 and rope.py:57-71).  All pointers are DEVICE pointers. */
+typedef struct ttv_batch {
+  int32_t n_clips;
+  int32_t total_rows;          /* L = sum(K_b + P_b) */
+  int32_t sum_tokens;          /* sum K_b */
+  int32_t sum_patches;         /* sum P_b */
+  int32_t max_patches_per_clip;
+  int32_t n_qblocks;
+  const int32_t* cu_seqlens;   /* [n_clips+1] */
+  const int32_t* latent_rows;  /* [sum_tokens]  packed row of every latent token, clip-major */
+  const int32_t* patch_rows;   /* [sum_patches] packed row of every patch token, clip-major */
+  const int32_t* clip_desc;    /* [n_clips,8] see ttv_patch_gather */
+  const int32_t* qblocks;      /* [n_qblocks,2] see ttv_attention */
+  const float* rope_cs;        /* [L,64] cos|sin, fp64-evaluated on the host as rope.py:48-54 */
+} ttv_batch;
+
+/* bytes of scratch a tower forward needs for this batch */
+int64_t ttv_tower_workspace_bytes(const ttv_tower_dims* dims, const ttv_batch* batch);
+
+/* TiTokEncoder.forward (blocks.py:71-104) + FSQ.forward (fsq.py:123-135) fused at the tail:
+ * clips (HOST array of device ptrs) -> z [sum_tokens, token_size] fp32 (pre-quantisation, may be NULL),
+ * codes [sum_tokens, token_size] (dtype), indices int32 [sum_tokens], bounded fp32 (may be NULL).
+ * If fsq == NULL only z is produced (used for the discriminator's encoder, loss_module.py:96-101). */
+int ttv_encoder_forward(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_batch* batch,
+                        const void* const* clips, const ttv_fsq_params* fsq, float* z, void* codes, int32_t* indices,
+                        float* bounded, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* TiTokDecoder.forward (blocks.py:148-177): codes [sum_tokens, token_size] (dtype) -> clips_out
+ * (HOST array of device ptrs to [C,T,H,W] buffers, dtype). */
+int ttv_decoder_forward(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_batch* batch, const void* codes,
+                        void* const* clips_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- codebook statistics (train_utils/codebook_logging.py:19-32) -------------------------------------- */
+/* counts[idx] += 1 for every index (int64 device histogram, atomics); usage/entropy are finished on the host. */
+int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int codebook_size, void* stream);
+
+/* ---- measurement hook (bench.py roofline leg) ---------------------------------------------------------- */
+/* Kernel classes whose launches can be bracketed by HIP events on the stream they are launched on. */
+#define TTV_KC_ATTENTION 1
+#define TTV_KC_GEMM_QKV 2
+#define TTV_KC_GEMM_GEGLU 3
+#define TTV_KC_GEMM_RESID 4
+#define TTV_KC_GEMM_STORE 5
+#define TTV_KC_RMSNORM 6
+#define TTV_KC_PATCH 7
+#define TTV_KC_ROWS 8
+/* Start recording launches of `kernel_class` (up to max_records; events are created here, outside any launch path).
+ * This is the only process-global state in the library and it is off by default. */
+int ttv_prof_begin(int kernel_class, int max_records);
+/* Synchronise the recorded events, return their summed duration (ms) and count, and release them. */
+int ttv_prof_end(double* total_ms, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TITOK_HIP_H */

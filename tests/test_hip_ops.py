@@ -1,0 +1,316 @@
+"""Per-kernel parity: every C-ABI op of libtitok_hip.so against the CPU oracle on the same seeded inputs.
+
+All tests need the MI355X (`-m gpu`).  Tolerances are written next to each comparison:
+  * integer outputs (FSQ indices, histogram) are bit-exact;
+  * fp32 kernels: differences come from summation order / libm only;
+  * bf16 kernels: inputs are bf16-rounded once for both sides; the kernel accumulates in fp32 and rounds its
+    output to bf16 once, so the bound is a few bf16 ulps (2^-8 relative) of the output magnitude.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import titok_oracle as O
+from titok_video_amd import _lib
+from titok_video_amd.model.quantizer.fsq import FSQ
+from titok_video_amd.plan import BatchPlan
+from titok_video_amd.synthetic import seeded_titok_state
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+DT = {"bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def L():
+    return _lib.lib()
+
+
+def S():
+    return _lib.stream_ptr(torch.device(DEV))
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def tol(dt):   # (relative Frobenius error, max-abs error as a fraction of max|ref|)
+    return (3e-3, 2e-2) if dt == "bf16" else (2e-6, 2e-5)
+
+
+def assert_close(out, ref, dt, scale=1.0):
+    r, m = tol(dt)
+    ref = ref.double().cpu()
+    out = out.double().cpu()
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < r * scale, rel_err(out, ref)
+    assert float((out - ref).abs().max()) <= m * scale * float(ref.abs().max() + 1e-30)
+
+
+# ---------------------------------------------------------------------------------------------- FSQ
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fsq_kat_bit_exact(tag):
+    d = np.load(os.path.join(G, "fsq_kat.npz"))
+    levels = d[f"levels_{tag}"].tolist()
+    f = FSQ(levels)
+    z = torch.from_numpy(d[f"z_{tag}"]).to(DEV)
+    codes, dd = f(z)
+    idx = dd["indices"].cpu().numpy()
+    bounded = f.bounded(z).cpu()
+    ref_idx, ref_b = d[f"indices_{tag}"], torch.from_numpy(d[f"bounded_{tag}"])
+    # tanhf on the device and torch's CPU tanh may differ in the last ulp: bounded agrees to 2 ulp of half_l ...
+    assert float((bounded - ref_b).abs().max()) < 2e-6
+    # ... so an index may only differ where the reference value sits within that distance of a rounding boundary
+    margin = O.fsq_margin(ref_b).numpy()
+    safe = margin > 4e-6
+    assert np.array_equal(idx[safe], ref_idx[safe])
+    assert (idx != ref_idx).sum() <= 2
+    assert np.array_equal(codes.cpu().numpy()[safe], d[f"codes_{tag}"][safe])
+    n = int(np.prod(levels))
+    cb = f.indices_to_codes(torch.arange(n, dtype=torch.int32, device=DEV)).cpu().numpy()
+    assert np.array_equal(cb, d[f"codebook_{tag}"])
+    assert np.array_equal(cb, f.implicit_codebook.numpy())
+    # round trip: quantising a codebook entry (scaled into the bound's linear range) returns its index
+    codes2, dd2 = f(torch.atanh(torch.from_numpy(cb).clamp(-0.999, 0.999)).to(DEV) * 0 + torch.from_numpy(cb).to(DEV) * 20)
+    assert idx.min() >= 0 and idx.max() < n
+
+
+def test_fsq_bf16_io_and_empty():
+    f = FSQ([8, 8, 8, 6, 5])
+    g = torch.Generator().manual_seed(1)
+    z = (torch.randn(1000, 5, generator=g) * 1.5).to(torch.bfloat16)
+    codes, dd = f(z.to(DEV))
+    rc, ri, rb = O.fsq_forward(z, [8, 8, 8, 6, 5])
+    safe = (O.fsq_margin(rb) > 1e-5).numpy()
+    assert np.array_equal(dd["indices"].cpu().numpy()[safe], ri.numpy()[safe])
+    assert torch.equal(codes.cpu()[torch.from_numpy(safe)], rc[torch.from_numpy(safe)])
+    c0, d0 = f(torch.empty(0, 5, device=DEV))
+    assert c0.shape == (0, 5) and d0["indices"].shape == (0,)
+
+
+# ---------------------------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("d", [256, 768, 1024])
+def test_rmsnorm(dt, d):
+    g = torch.Generator().manual_seed(d)
+    rows = 37
+    x = (torch.randn(rows, d, generator=g) * 3).to(DT[dt])
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    src = torch.randperm(rows, generator=g).to(torch.int32)
+    dst = torch.randperm(rows + 5, generator=g)[:rows].to(torch.int32)
+    out = torch.zeros(rows + 5, d, dtype=DT[dt], device=DEV)
+    xd, wd, sd, dd = x.to(DEV), w.to(DEV), src.to(DEV), dst.to(DEV)
+    code = _lib.dtype_code(DT[dt])
+    _lib.check(L().ttv_rmsnorm(xd.data_ptr(), code, d, sd.data_ptr(), out.data_ptr(), code, d, dd.data_ptr(), wd.data_ptr(),
+                               rows, d, 1e-5, S()), "rmsnorm")
+    ref = torch.zeros(rows + 5, d)
+    ref[dst.long()] = O.rmsnorm(x[src.long()], w).float()
+    assert_close(out.float(), ref, dt)
+    # fp32 in -> bf16 out (the KEEL post-norm path)
+    if dt == "bf16":
+        xf = torch.randn(rows, d, generator=g) * 10
+        o2 = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+        xfd = xf.to(DEV)
+        _lib.check(L().ttv_rmsnorm(xfd.data_ptr(), _lib.TTV_F32, d, None, o2.data_ptr(), _lib.TTV_BF16, d, None, wd.data_ptr(),
+                                   rows, d, 1e-5, S()), "rmsnorm")
+        assert_close(o2.float(), O.rmsnorm(xf, w), "bf16")
+
+
+# ---------------------------------------------------------------------------------------------- RoPE
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_rope_apply_matches_reference_fixture(dt):
+    d = np.load(os.path.join(G, "rope_kat.npz"))
+    grids, counts = d["grids_1"].tolist(), d["counts_1"].tolist()
+    plan = BatchPlan([(g[0] * 4, g[1] * 8, g[2] * 8) for g in grids], counts, (4, 8, 8), DEV)
+    # host table == reference freqs_cis (fp64 -> fp32)
+    cs = plan.rope_cs.cpu().numpy()
+    assert np.array_equal(cs[:, :30], d["cos_1"].astype(np.float32))
+    assert np.array_equal(cs[:, 32:62], d["sin_1"].astype(np.float32))
+    assert np.all(cs[:, 30:32] == 1) and np.all(cs[:, 62:] == 0)
+    q = torch.from_numpy(d["rot_q"]).to(DT[dt])
+    qd = q.to(DEV).contiguous()
+    _lib.check(L().ttv_rope_apply(qd.data_ptr(), _lib.dtype_code(DT[dt]), 256, q.shape[0], 4, plan.rope_cs.data_ptr(), S()), "rope")
+    if dt == "f32":
+        np.testing.assert_allclose(qd.cpu().numpy(), d["rot_out"], rtol=0, atol=2e-6)
+        assert np.array_equal(qd.cpu().numpy()[..., 60:], d["rot_q"][..., 60:])
+    else:
+        cos, sin = O.rope_table(grids, counts)
+        assert_close(qd.float(), O.apply_rotary(q.float(), cos, sin), "bf16")
+
+
+# ---------------------------------------------------------------------------------------------- linear layers
+def _lin_inputs(M, N, K, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g).to(DT[dt])
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DT[dt])
+    return x, w, g
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(300, 256, 768), (129, 768, 256), (64, 8, 256), (1, 256, 704), (513, 256, 1376)])
+def test_linear_bias_scalar(dt, shape):
+    M, N, K = shape
+    x, w, g = _lin_inputs(M, N, K, dt, M + N)
+    b = (torch.randn(N, generator=g) * 0.1).to(DT[dt])
+    sc = torch.tensor([0.37])
+    y = torch.empty(M, N, dtype=DT[dt], device=DEV)
+    xd, wd, bd, sd = x.to(DEV), w.to(DEV), b.to(DEV), sc.to(DEV)
+    _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), sd.data_ptr(), y.data_ptr(), N, M, N, K,
+                              _lib.dtype_code(DT[dt]), S()), "linear")
+    ref = x.double() @ w.double().T + b.double() + float(sc.to(DT[dt]))
+    assert_close(y.float(), ref, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_linear_qkv_rope(dt):
+    plan = BatchPlan([(8, 32, 48), (4, 16, 24)], [3, 5], (4, 8, 8), DEV)
+    M, d, gq = plan.total_rows, 256, 128
+    x, w, g = _lin_inputs(M, 2 * d + 2 * gq, d, dt, 5)
+    y = torch.empty(M, 2 * d + 2 * gq, dtype=DT[dt], device=DEV)
+    xd, wd = x.to(DEV), w.to(DEV)
+    _lib.check(L().ttv_linear_qkv_rope(xd.data_ptr(), d, wd.data_ptr(), d, y.data_ptr(), 2 * d + 2 * gq, M, d, gq,
+                                       plan.rope_cs.data_ptr(), _lib.dtype_code(DT[dt]), S()), "qkv")
+    ref = (x.double() @ w.double().T).float()
+    q, gate, k, v = ref.split([d, d, gq, gq], dim=-1)
+    cos, sin = O.rope_table(plan.grids, plan.token_counts)
+    q = O.apply_rotary(q.unflatten(-1, (4, 64)), cos, sin).flatten(-2)
+    k = O.apply_rotary(k.unflatten(-1, (2, 64)), cos, sin).flatten(-2)
+    assert_close(y.float(), torch.cat([q, gate, k, v], -1), dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("I", [704, 1376, 96])
+def test_linear_geglu(dt, I):
+    M, K = 257, 256
+    x, w, g = _lin_inputs(M, 2 * I, K, dt, I)
+    y = torch.empty(M, I, dtype=DT[dt], device=DEV)
+    xd, wd = x.to(DEV), w.to(DEV)
+    _lib.check(L().ttv_linear_geglu(xd.data_ptr(), K, wd.data_ptr(), K, y.data_ptr(), I, M, I, K, _lib.dtype_code(DT[dt]), S()), "geglu")
+    h = x.double() @ w.double().T
+    a, gate = h.chunk(2, -1)
+    assert_close(y.float(), torch.nn.functional.gelu(gate) * a, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("f32out", [0, 1])
+def test_linear_residual(dt, f32out):
+    M, N, K = 200, 256, 704
+    x, w, g = _lin_inputs(M, N, K, dt, 9)
+    r = torch.randn(M, N, generator=g).to(DT[dt])
+    y = torch.empty(M, N, dtype=torch.float32 if f32out else DT[dt], device=DEV)
+    xd, wd, rd = x.to(DEV), w.to(DEV), r.to(DEV)
+    _lib.check(L().ttv_linear_residual(xd.data_ptr(), K, wd.data_ptr(), K, rd.data_ptr(), N, 8.0, y.data_ptr(), N, f32out, M, N, K,
+                                       _lib.dtype_code(DT[dt]), S()), "resid")
+    ref = 8.0 * r.double() + x.double() @ w.double().T
+    assert_close(y.float(), ref, "f32" if (f32out and dt == "f32") else dt)
+    if not f32out:   # in place on the residual (layer-0 path)
+        _lib.check(L().ttv_linear_residual(xd.data_ptr(), K, wd.data_ptr(), K, rd.data_ptr(), N, 1.0, rd.data_ptr(), N, 0, M, N, K,
+                                           _lib.dtype_code(DT[dt]), S()), "resid")
+        assert_close(rd.float(), r.double() + x.double() @ w.double().T, dt)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("case", [([(4, 16, 16)], [1]), ([(8, 32, 48), (4, 8, 24), (16, 64, 64)], [5, 3, 128]),
+                                  ([(16, 128, 128)], [128]), ([(4, 8, 8), (4, 8, 8)], [0, 63])])
+@pytest.mark.parametrize("heads", [(4, 2), (12, 4)])
+def test_attention_varlen_gqa_gate(dt, case, heads):
+    shapes, counts = case
+    plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
+    hq, hkv = heads
+    d, gq = hq * 64, hkv * 64
+    ld = 2 * d + 2 * gq
+    g = torch.Generator().manual_seed(len(shapes) + hq)
+    qkvg = torch.randn(plan.total_rows, ld, generator=g)
+    qkvg[:, :d] *= 2.0            # sharper softmax
+    qkvg = qkvg.to(DT[dt])
+    out = torch.empty(plan.total_rows, d, dtype=DT[dt], device=DEV)
+    xd = qkvg.to(DEV)
+    for gate in (1, 0):
+        _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(),
+                                     plan.n_qblocks, hq, hkv, 64, gate, _lib.dtype_code(DT[dt]), S()), "attention")
+        f = qkvg.float()
+        q, gt, k, v = f.split([d, d, gq, gq], dim=-1)
+        ref = O.attention_varlen(q.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)),
+                                 plan.cu_seqlens).flatten(-2)
+        if gate:
+            ref = ref * torch.sigmoid(gt)
+        assert_close(out.float(), ref, dt, scale=2.0 if dt == "bf16" else 5.0)
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump at a late key tile (spike one key against every query)."""
+    plan = BatchPlan([(8, 32, 32)], [7], (4, 8, 8), DEV)   # S = 39 ... use a longer one
+    plan = BatchPlan([(16, 64, 64)], [9], (4, 8, 8), DEV)  # S = 265 -> 5 key tiles
+    hq, hkv, d, gq = 4, 2, 256, 128
+    ld = 2 * d + 2 * gq
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(plan.total_rows, ld, generator=g) * 0.5
+    q = x[:, :d].view(-1, 4, 64)
+    x[200, 2 * d: 2 * d + gq] = 6.0 * torch.sign(q[5, 0]).repeat(2)   # key 200 (4th tile) dominates
+    x = x.to(torch.bfloat16)
+    out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
+    xd = x.to(DEV)
+    _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(),
+                                 plan.n_qblocks, hq, hkv, 64, 0, _lib.TTV_BF16, S()), "attention")
+    f = x.float()
+    qq, gt, k, v = f.split([d, d, gq, gq], dim=-1)
+    ref = O.attention_varlen(qq.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)
+    assert_close(out.float(), ref, "bf16", scale=2.0)
+
+
+# ---------------------------------------------------------------------------------------------- patches
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_patch_gather_scatter(dt):
+    shapes = [(8, 16, 24), (4, 8, 8), (16, 32, 16)]
+    plan = BatchPlan(shapes, [1, 1, 1], (4, 8, 8), DEV)
+    g = torch.Generator().manual_seed(2)
+    clips = [torch.randn(3, *s, generator=g).to(DT[dt]) for s in shapes]
+    cd = [c.to(DEV) for c in clips]
+    pd = 768
+    patches = torch.empty(plan.sum_patches, pd, dtype=DT[dt], device=DEV)
+    code = _lib.dtype_code(DT[dt])
+    _lib.check(L().ttv_patch_gather(_lib.ptr_array(cd), plan.clip_desc_dev.data_ptr(), 0, 3, 4, 8, 8, 3, patches.data_ptr(), pd, code,
+                                    max(plan.grid_sizes), S()), "gather")
+    perm = torch.arange(768).reshape(4, 8, 8, 3).permute(3, 0, 1, 2).reshape(-1)   # (c,pt,ph,pw) <- (pt,ph,pw,c)
+    ref = torch.cat([O.patchify(c, (4, 8, 8)) for c in clips], 0)[:, perm]
+    assert torch.equal(patches.cpu(), ref)        # pure data movement: bit-exact
+    outs = [torch.zeros_like(c) for c in cd]
+    _lib.check(L().ttv_patch_scatter(patches.data_ptr(), pd, plan.clip_desc_dev.data_ptr(), 0, 3, 4, 8, 8, 3, _lib.ptr_array(outs), code,
+                                     max(plan.grid_sizes), S()), "scatter")
+    for o, c in zip(outs, clips):
+        assert torch.equal(o.cpu(), c)
+
+
+def test_patch_kat_matches_reference_fixture():
+    d = np.load(os.path.join(G, "patch_kat.npz"))
+    clip = torch.from_numpy(d["clip"]).to(DEV)
+    plan = BatchPlan([tuple(clip.shape[1:])], [1], (4, 8, 8), DEV)
+    patches = torch.empty(plan.sum_patches, 768, dtype=torch.float32, device=DEV)
+    _lib.check(L().ttv_patch_gather(_lib.ptr_array([clip]), plan.clip_desc_dev.data_ptr(), 0, 1, 4, 8, 8, 3, patches.data_ptr(), 768,
+                                    _lib.TTV_F32, plan.sum_patches, S()), "gather")
+    inv = torch.empty(768, dtype=torch.long)
+    inv[torch.arange(768).reshape(4, 8, 8, 3).permute(3, 0, 1, 2).reshape(-1)] = torch.arange(768)
+    assert np.array_equal(patches.cpu()[:, inv].numpy(), d["patches"])
+
+
+# ---------------------------------------------------------------------------------------------- histogram
+def test_codebook_histogram():
+    g = torch.Generator().manual_seed(4)
+    idx = torch.randint(0, 4375, (100000,), generator=g, dtype=torch.int32)
+    counts = torch.zeros(4375, dtype=torch.int64, device=DEV)
+    idd = idx.to(DEV)
+    _lib.check(L().ttv_codebook_histogram(idd.data_ptr(), idx.numel(), counts.data_ptr(), 4375, S()), "hist")
+    assert torch.equal(counts.cpu(), torch.bincount(idx.long(), minlength=4375))
+
+
+def test_errors_are_loud():
+    with pytest.raises(RuntimeError, match="HIP"):
+        FSQ([7, 5, 5, 5, 5])(torch.zeros(3, 5))            # CPU tensor: no fallback
+    x = torch.zeros(4, 100, device=DEV)
+    with pytest.raises(RuntimeError, match="K="):
+        _lib.check(L().ttv_linear(x.data_ptr(), 100, x.data_ptr(), 100, None, None, x.data_ptr(), 4, 4, 4, 98, _lib.TTV_F32, S()), "linear")

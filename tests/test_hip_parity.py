@@ -1,0 +1,215 @@
+"""End-to-end parity of the HIP towers / TiTok facade against fixtures produced by the reference's own code
+(tests/golden/*.npz) and against the CPU oracle on the same seeded inputs.  `-m gpu`.
+
+Parity bars
+  * fp32 compute  : token indices BIT-EXACT vs the reference on every fixture token whose FSQ rounding margin
+                    0.5-|b-round(b)| exceeds 1e-3 (all tokens of the small fixtures); z / pixels to ~1e-3.
+  * bf16 compute  : (the configuration the benchmark runs) indices exact on tokens with margin > TAU_BF16, raw match
+                    rate reported and bounded below; pixels within PIX_TOL_BF16 (max-abs on a [-1,1]-scaled signal with
+                    std ~1.9) and 2.5% relative Frobenius error.  SURVEY.md R8: the reference's own bf16 vs fp32 runs
+                    agree on only 94.9% of indices, so bf16 can not be bit-exact by construction.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import titok_oracle as O
+from titok_video_amd.model.base.blocks import TiTokEncoder
+from titok_video_amd.model.titok import TiTok
+from titok_video_amd.synthetic import seeded_titok_state, seeded_tower_state, synthetic_clips
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+LEVELS = [7, 5, 5, 5, 5]
+TAU_F32 = 1e-3
+TAU_BF16 = 0.08
+PIX_TOL_BF16 = 0.25
+
+
+def config(levels=LEVELS, enc="tiny", dec="tiny"):
+    return SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(
+        patch_size=[4, 8, 8], fsq_levels=list(levels), encoder_size=enc, decoder_size=dec)))
+
+
+def build(dtype, seed=0, **kw):
+    m = TiTok(config(**kw))
+    m.load_state_dict(seeded_titok_state(seed, encoder_size=kw.get("enc", "tiny"), decoder_size=kw.get("dec", "tiny")), strict=True)
+    return m.to(DEV, dtype).eval()
+
+
+def fixture_inputs(d, dtype):
+    if "shapes" in d:
+        shapes, counts = d["shapes"].tolist(), d["counts"].tolist()
+    else:
+        shapes, counts = [d["shape"].tolist()], [int(d["count"])]
+    clips = synthetic_clips(shapes, seed=int(d["clip_seed"]), dtype=dtype, device=DEV)
+    return shapes, counts, clips
+
+
+def run(model, clips, counts):
+    with torch.no_grad():
+        codes, dd = model.encode(clips, counts, want_bounded=True)
+        recon = model.decode(codes, counts, [tuple(c.shape[1:]) for c in clips])
+    torch.cuda.synchronize()
+    return codes, dd["indices"].cpu().numpy(), model.last_bounded.cpu(), recon
+
+
+@pytest.mark.parametrize("name", ["titok_small.npz", "titok_single.npz"])
+def test_fp32_bit_exact_indices_vs_reference(name):
+    d = np.load(os.path.join(G, name))
+    model = build(torch.float32)
+    shapes, counts, clips = fixture_inputs(d, torch.float32)
+    codes, idx, bounded, recon = run(model, clips, counts)
+    assert np.array_equal(idx, d["indices"])                     # every token, bit-exact
+    np.testing.assert_allclose(bounded.numpy(), d["bounded"], rtol=0, atol=2e-3)
+    refs = [d[f"recon_{i}"] for i in range(len(recon))] if "recon_0" in d else [d["recon"]]
+    for r, ref in zip(recon, refs):
+        np.testing.assert_allclose(r.cpu().numpy(), ref, rtol=0, atol=5e-3)
+
+
+def test_fp32_cfg1_vs_reference():
+    """BASELINE config #1 shapes (4 x 16x128x128, K=128)."""
+    d = np.load(os.path.join(G, "titok_cfg1.npz"))
+    model = build(torch.float32)
+    shapes, counts, clips = fixture_inputs(d, torch.float32)
+    codes, idx, bounded, recon = run(model, clips, counts)
+    margin = O.fsq_margin(torch.from_numpy(d["bounded"])).numpy()
+    safe = margin > TAU_F32
+    assert np.array_equal(idx[safe], d["indices"][safe])
+    raw = float((idx == d["indices"]).mean())
+    print(f"cfg1 fp32: raw index match {raw:.4f}, tokens with margin>{TAU_F32}: {safe.mean():.4f}")
+    assert raw > 0.99
+    rs = torch.stack([r.float().cpu() for r in recon])
+    np.testing.assert_allclose(rs[:, :, ::4, ::8, ::8].numpy(), d["recon_sample"], rtol=0, atol=2e-2)
+    assert abs(float(rs.double().std()) - float(d["recon_std"])) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["titok_small.npz", "titok_cfg1.npz"])
+def test_bf16_vs_reference(name):
+    d = np.load(os.path.join(G, name))
+    model = build(torch.bfloat16)
+    shapes, counts, clips = fixture_inputs(d, torch.bfloat16)
+    codes, idx, bounded, recon = run(model, clips, counts)
+    margin = O.fsq_margin(torch.from_numpy(d["bounded"])).numpy()
+    safe = margin > TAU_BF16
+    raw = float((idx == d["indices"]).mean())
+    berr = float((bounded - torch.from_numpy(d["bounded"])).abs().max())
+    print(f"{name} bf16: raw index match {raw:.4f}; safe fraction {safe.mean():.3f}; max |bounded err| {berr:.4f}")
+    assert np.array_equal(idx[safe], d["indices"][safe])
+    assert raw >= 0.90
+    assert berr < TAU_BF16
+    if "recon_0" in d:
+        for i, r in enumerate(recon):
+            ref = torch.from_numpy(d[f"recon_{i}"])
+            # a flipped token changes its clip's pixels legitimately: compare pixels through decode of the REFERENCE codes below
+    # decoder alone on the reference's codes (no dependence on index flips)
+    ref_codes = O.fsq_indices_to_codes(torch.from_numpy(d["indices"]), LEVELS).to(torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        rec2 = model.decode(ref_codes, counts, shapes)
+    if "recon_0" in d:
+        for i, r in enumerate(rec2):
+            ref = torch.from_numpy(d[f"recon_{i}"])
+            err = (r.float().cpu() - ref)
+            assert float(err.abs().max()) < PIX_TOL_BF16
+            assert float(err.norm() / ref.norm()) < 0.025
+    else:
+        rs = torch.stack([r.float().cpu() for r in rec2])[:, :, ::4, ::8, ::8]
+        ref = torch.from_numpy(d["recon_sample"])
+        assert float((rs - ref).abs().max()) < PIX_TOL_BF16
+        assert float((rs - ref).norm() / ref.norm()) < 0.025
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_api_contract(dtype):
+    """Shapes / dtypes / list-of-clips API of model/titok.py:47-74; decode_indices == decode."""
+    model = build(dtype)
+    shapes = [(4, 16, 16), (8, 32, 48), (4, 8, 24)]
+    counts = [2, 5, 3]
+    clips = synthetic_clips(shapes, seed=5, dtype=dtype, device=DEV)
+    tc = torch.tensor(counts, dtype=torch.int32, device=DEV)       # the reference passes a device tensor
+    with torch.no_grad():
+        recon, out = model(clips, tc)
+        assert out["indices"].dtype == torch.int32 and out["indices"].shape == (10,)
+        assert all(r.shape == c.shape and r.dtype == dtype and r.device == c.device for r, c in zip(recon, clips))
+        x_q, od = model.encode(clips, tc, grids=torch.tensor(shapes, dtype=torch.int32, device=DEV))
+        assert x_q.shape == (10, 5) and x_q.dtype == dtype
+        assert torch.equal(od["indices"], out["indices"])
+        a = model.decode(x_q, tc, shapes)
+        b = model.decode_indices(od["indices"], shapes, tc)
+        c = model.decode_indices(list(torch.split(od["indices"], counts)), shapes)
+        for u, v, w, r in zip(a, b, c, recon):
+            assert torch.equal(u, v) and torch.equal(u, w) and torch.equal(u, r)
+        _, sp = model.encode(clips, counts, split_indices=True)
+        assert [int(t.shape[0]) for t in sp["indices"]] == counts
+        # FSQ consistency: indices_to_codes(indices) == codes
+        assert torch.equal(model.quantize.indices_to_codes(od["indices"], dtype=dtype), x_q)
+        assert int(od["indices"].min()) >= 0 and int(od["indices"].max()) < model.quantize.codebook_size
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packing_invariance(dtype):
+    """A clip's tokens and pixels must not depend on its batch mates (block-diagonal attention, transformer.py:100)."""
+    model = build(dtype)
+    shapes = [(8, 32, 48), (4, 16, 16), (16, 64, 32)]
+    counts = [5, 1, 17]
+    clips = synthetic_clips(shapes, seed=11, dtype=dtype, device=DEV)
+    with torch.no_grad():
+        recon, out = model(clips, counts)
+        for i in range(3):
+            r1, o1 = model([clips[i]], [counts[i]])
+            s = sum(counts[:i])
+            assert torch.equal(o1["indices"], out["indices"][s:s + counts[i]])
+            assert torch.equal(r1[0], recon[i])
+
+
+def test_discriminator_style_encoder_call():
+    """ReconstructionLoss builds TiTokEncoder(out_channels=1) and calls it with K=4 register tokens (loss_module.py:43-48,96-101)."""
+    enc = TiTokEncoder(model_size="tiny", patch_size=(4, 8, 8), in_channels=3, out_channels=1)
+    sd = seeded_tower_state("encoder", "tiny", (4, 8, 8), 3, 1, seed=77)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV, torch.float32)
+    shapes = [(8, 16, 16), (4, 24, 16)]
+    clips = synthetic_clips(shapes, seed=3, dtype=torch.float32, device=DEV)
+    tc = torch.tensor([4, 4], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        logits = enc(clips, tc)
+    assert logits.shape == (8, 1)
+    ref = O.encoder_forward([c.cpu() for c in clips], [4, 4], sd, "tiny", (4, 8, 8))
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-3)
+
+
+def test_blocks_kat_fp32():
+    """Transformer stack alone vs the reference fixture (Attn + GEGLU + KEEL layers), through the encoder's kernels."""
+    import ctypes as C
+    from titok_video_amd import _lib
+    from titok_video_amd.plan import BatchPlan
+    d = np.load(os.path.join(G, "blocks_kat.npz"))
+    sd = seeded_titok_state(int(d["weight_seed"]))
+    grids, counts = d["grids"].tolist(), d["counts"].tolist()
+    plan = BatchPlan([(g[0] * 4, g[1] * 8, g[2] * 8) for g in grids], counts, (4, 8, 8), DEV)
+    x = torch.from_numpy(d["x"]).to(DEV)
+    Lr, dm, gq, I = x.shape[0], 256, 128, 704
+    S = _lib.stream_ptr(torch.device(DEV))
+    lib = _lib.lib()
+    p = "encoder.model_layers."
+    w = {k: v.to(DEV) for k, v in sd.items() if k.startswith(p)}
+    # attention sub-layer 1
+    xn = torch.empty_like(x)
+    _lib.check(lib.ttv_rmsnorm(x.data_ptr(), 1, dm, None, xn.data_ptr(), 1, dm, None, w[p + "attn_layer.1.pre_ln.weight"].data_ptr(), Lr, dm, 1e-5, S), "n")
+    qkv = torch.empty(Lr, 2 * dm + 2 * gq, device=DEV)
+    _lib.check(lib.ttv_linear_qkv_rope(xn.data_ptr(), dm, w[p + "attn_layer.1.to_qkv.weight"].data_ptr(), dm, qkv.data_ptr(), 2 * dm + 2 * gq, Lr, dm, gq, plan.rope_cs.data_ptr(), 1, S), "q")
+    ao = torch.empty(Lr, dm, device=DEV)
+    _lib.check(lib.ttv_attention(qkv.data_ptr(), 2 * dm + 2 * gq, ao.data_ptr(), dm, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(), plan.n_qblocks, 4, 2, 64, 1, 1, S), "a")
+    out = torch.empty(Lr, dm, device=DEV)
+    _lib.check(lib.ttv_linear(ao.data_ptr(), dm, w[p + "attn_layer.1.out_proj.weight"].data_ptr(), dm, None, None, out.data_ptr(), dm, Lr, dm, dm, 1, S), "o")
+    np.testing.assert_allclose(out.cpu().numpy(), d["attn1"], rtol=1e-3, atol=1e-3)
+    # GEGLU sub-layer 1
+    _lib.check(lib.ttv_rmsnorm(x.data_ptr(), 1, dm, None, xn.data_ptr(), 1, dm, None, w[p + "ffd_layer.1.norm.weight"].data_ptr(), Lr, dm, 1e-5, S), "n")
+    h = torch.empty(Lr, I, device=DEV)
+    _lib.check(lib.ttv_linear_geglu(xn.data_ptr(), dm, w[p + "ffd_layer.1.w12.weight"].data_ptr(), dm, h.data_ptr(), I, Lr, I, dm, 1, S), "g")
+    _lib.check(lib.ttv_linear(h.data_ptr(), I, w[p + "ffd_layer.1.w3.weight"].data_ptr(), I, None, None, out.data_ptr(), dm, Lr, dm, I, 1, S), "o")
+    np.testing.assert_allclose(out.cpu().numpy(), d["ffd1"], rtol=1e-3, atol=1e-3)

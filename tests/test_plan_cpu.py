@@ -1,0 +1,90 @@
+"""Host logic: batch plan tables (cu_seqlens, row maps, q-blocks, RoPE table) against the oracle / reference fixtures;
+module state-dict compatibility with the reference's key names.  CPU only."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import titok_oracle as O
+from titok_video_amd.plan import BatchPlan, get_plan, host_ints
+from titok_video_amd.model.titok import TiTok
+from titok_video_amd.model.quantizer.fsq import FSQ
+from titok_video_amd.synthetic import seeded_titok_state, tower_param_shapes
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_plan_tables_match_oracle_metadata():
+    shapes = [(8, 32, 48), (4, 8, 24), (16, 128, 128), (4, 8, 8)]
+    counts = [5, 0, 128, 1]
+    plan = BatchPlan(shapes, counts, (4, 8, 8), "cpu")
+    grids, sizes, cts, cu, mask = O.batch_metadata(shapes, counts, (4, 8, 8))
+    assert plan.cu_seqlens == cu and plan.grid_sizes == sizes
+    assert plan.cu_dev.tolist() == cu
+    rows = torch.arange(len(mask))
+    assert plan.latent_rows_dev.tolist() == rows[mask].tolist()
+    assert plan.patch_rows_dev.tolist() == rows[~mask].tolist()
+    qb = plan.qblocks_dev.view(-1, 2).tolist()
+    covered = []
+    for b, q0 in qb:
+        s = cu[b + 1] - cu[b]
+        assert q0 % 128 == 0 and q0 < s
+        covered += [(b, r) for r in range(q0, min(q0 + 128, s))]
+    assert len(covered) == cu[-1] == len(set(covered))
+    desc = plan.clip_desc_dev.view(-1, 8)
+    assert desc[:, 6].tolist() == [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]
+
+
+def test_plan_rope_table_is_reference_bits():
+    d = np.load(os.path.join(G, "rope_kat.npz"))
+    for i in range(4):
+        grids, counts = d[f"grids_{i}"].tolist(), d[f"counts_{i}"].tolist()
+        plan = BatchPlan([(g[0] * 4, g[1] * 8, g[2] * 8) for g in grids], counts, (4, 8, 8), "cpu")
+        cs = plan.rope_cs.numpy()
+        assert np.array_equal(cs[:, :30], d[f"cos_{i}"].astype(np.float32))
+        assert np.array_equal(cs[:, 32:62], d[f"sin_{i}"].astype(np.float32))
+        assert np.all(cs[:, 30:32] == 1.0) and np.all(cs[:, 62:64] == 0.0)
+
+
+def test_plan_rejects_bad_shapes_and_caches():
+    with pytest.raises(ValueError):
+        BatchPlan([(5, 8, 8)], [1], (4, 8, 8), "cpu")
+    with pytest.raises(ValueError):
+        BatchPlan([(4, 8, 8)], [1, 2], (4, 8, 8), "cpu")
+    a = get_plan([(4, 8, 8)], [3], (4, 8, 8), "cpu")
+    b = get_plan([[4, 8, 8]], torch.tensor([3]).tolist(), [4, 8, 8], "cpu")
+    assert a is b
+    assert host_ints(torch.tensor([[4, 8, 8]], dtype=torch.int32)) == [[4, 8, 8]]
+
+
+def test_state_dict_keys_and_param_count_match_reference():
+    cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(
+        patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5], encoder_size="tiny", decoder_size="tiny")))
+    m = TiTok(cfg)
+    keys = list(m.state_dict().keys())
+    expect = ["encoder." + k for k in tower_param_shapes("encoder", "tiny", (4, 8, 8), 3, 5)] + \
+             ["decoder." + k for k in tower_param_shapes("decoder", "tiny", (4, 8, 8), 5, 3)]
+    assert sorted(keys) == sorted(expect)                       # FSQ contributes no keys (non-persistent buffers)
+    assert sum(p.numel() for p in m.parameters()) == 6828295
+    m.load_state_dict(seeded_titok_state(0), strict=True)
+    # reference init (utils.py:54-66): gains 1, biases 0, |w| <= 2 std
+    m2 = TiTok(cfg)
+    with torch.no_grad():
+        assert float(m2.encoder.ln_post.weight.min()) == 1.0 and float(m2.decoder.proj_out.bias.abs().max()) == 0.0
+        assert abs(float(m2.encoder.model_layers.attn_layer[0].to_qkv.weight.std()) - 0.02) < 2e-3
+
+
+def test_fsq_module_constants_match_reference_module_api():
+    d = np.load(os.path.join(G, "fsq_kat.npz"))
+    f = FSQ([7, 5, 5, 5, 5])
+    assert f.codebook_size == 4375 and f.codebook_dim == 5 and f.dim == 5
+    assert f._basis.tolist() == [1, 7, 35, 175, 875]
+    assert np.array_equal(f.implicit_codebook.numpy(), d["codebook_a"])
+    z = torch.from_numpy(d["z_a"])
+    assert np.array_equal(f.bound(z).numpy(), d["bounded_a"])
+    assert np.array_equal(f.codes_to_indices(torch.from_numpy(d["codes_a"])).numpy(), d["indices_a"])
+    assert list(f.state_dict().keys()) == []
+    with pytest.raises(RuntimeError):
+        f(z)          # CPU tensor: the hot path has no fallback

@@ -1,0 +1,137 @@
+"""ctypes binding of libtitok_hip.so (C-ABI declared in include/titok_hip.h).
+
+The library is loaded on first use.  If it is missing the call raises: there is no eager-PyTorch or CPU
+fallback behind these entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+TTV_BF16, TTV_F32 = 0, 1
+TTV_ENCODER, TTV_DECODER = 0, 1
+TTV_MAX_FSQ = 8
+TTV_MAX_CLIPS_PER_LAUNCH = 64
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtitok_hip.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class FsqParams(C.Structure):
+    _fields_ = [("n", i32), ("levels", i32 * TTV_MAX_FSQ), ("basis", i32 * TTV_MAX_FSQ),
+                ("half_l", f32 * TTV_MAX_FSQ), ("offset", f32 * TTV_MAX_FSQ), ("shift", f32 * TTV_MAX_FSQ),
+                ("half_width", f32 * TTV_MAX_FSQ)]
+
+
+class TowerDims(C.Structure):
+    _fields_ = [("kind", i32), ("dtype", i32), ("width", i32), ("layers", i32), ("q_heads", i32), ("kv_heads", i32),
+                ("head_dim", i32), ("inner", i32), ("patch_t", i32), ("patch_h", i32), ("patch_w", i32),
+                ("pix_channels", i32), ("token_size", i32), ("eps", f32), ("alpha", f32)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
+                ("attn_post_ln", vp), ("ffd_post_ln", vp)]
+
+
+class TowerWeights(C.Structure):
+    _fields_ = [("proj_in_w", vp), ("proj_in_b", vp), ("mask_token", vp), ("ln_pre_t", vp), ("ln_pre_p", vp),
+                ("ln_post", vp), ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerWeights))]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_clips", i32), ("total_rows", i32), ("sum_tokens", i32), ("sum_patches", i32),
+                ("max_patches_per_clip", i32), ("n_qblocks", i32), ("cu_seqlens", vp), ("latent_rows", vp),
+                ("patch_rows", vp), ("clip_desc", vp), ("qblocks", vp), ("rope_cs", vp)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+# every symbol include/titok_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ttv_error_string": (C.c_char_p, []),
+    "ttv_version": (C.c_int, []),
+    "ttv_fsq_forward": (C.c_int, [C.POINTER(FsqParams), vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
+    "ttv_fsq_indices_to_codes": (C.c_int, [C.POINTER(FsqParams), vp, C.c_int, vp, C.c_int, vp]),
+    "ttv_rmsnorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, f32, vp]),
+    "ttv_rope_apply": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ttv_linear": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_linear_qkv_rope": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ttv_linear_geglu": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_linear_residual": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, vp]),
+    "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
+                                   C.c_int, C.c_int, vp]),
+    "ttv_patch_scatter": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp),
+                                    C.c_int, C.c_int, vp]),
+    "ttv_tower_workspace_bytes": (i64, [C.POINTER(TowerDims), C.POINTER(Batch)]),
+    "ttv_encoder_forward": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(Batch), C.POINTER(vp),
+                                      C.POINTER(FsqParams), vp, vp, vp, vp, vp, i64, vp]),
+    "ttv_decoder_forward": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(Batch), vp, C.POINTER(vp),
+                                      vp, i64, vp]),
+    "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
+    "ttv_prof_begin": (C.c_int, [C.c_int, C.c_int]),
+    "ttv_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+KERNEL_CLASSES = {"attention": 1, "gemm_qkv": 2, "gemm_geglu": 3, "gemm_resid": 4, "gemm_store": 5, "rmsnorm": 6,
+                  "patch": 7, "rows": 8}
+
+
+def lib():
+    """The loaded library (raises RuntimeError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"titok_video_amd: {LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (or titok_video_amd/csrc/build.sh). There is no non-HIP fallback.")
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in SYMBOLS.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ttv_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return TTV_BF16
+    if dt == torch.float32:
+        return TTV_F32
+    raise TypeError(f"titok_video_amd supports bfloat16 and float32 activations, got {dt}")
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; titok_video_amd runs on MI355X (HIP) only, there is no CPU path")
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    arr = (vp * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,322 @@
+// C-ABI of libtitok_hip.so (include/titok_hip.h): argument checks, workspace carving and the launch
+// sequences of the encoder / decoder towers.  Everything here only enqueues on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ttv_common.h"
+#include "ttv_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void ttv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- measurement hook ----
+int g_ttv_prof_class = 0;
+static hipEvent_t* g_prof_start = nullptr;
+static hipEvent_t* g_prof_stop = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+
+TtvProfScope::TtvProfScope(int cls, hipStream_t stream) : slot(-1), s(stream) {
+  if (g_ttv_prof_class != 0 && cls == g_ttv_prof_class && g_prof_n < g_prof_cap) {
+    slot = g_prof_n++;
+    (void)hipEventRecord(g_prof_start[slot], s);
+  }
+}
+TtvProfScope::~TtvProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof_stop[slot], s);
+}
+
+#define TTV_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != TTV_OK) return rc__; \
+  } while (0)
+
+static inline int esize(int dtype) { return dtype == TTV_BF16 ? 2 : 4; }
+static inline int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+struct TowerWs {
+  char *x, *xn, *qkv, *ao, *h, *pa, *pb;
+  float* y32;
+  int64_t total;
+};
+
+static TowerWs carve(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
+  const int64_t e = esize(d->dtype);
+  const int64_t L = b->total_rows, P = b->sum_patches;
+  const int64_t g = (int64_t)d->kv_heads * d->head_dim;
+  const int64_t pd = (int64_t)d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  int64_t off = 0;
+  TowerWs w;
+  auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+  w.x = take(L * d->width * e);
+  w.xn = take(L * d->width * e);
+  w.qkv = take(L * (2 * d->width + 2 * g) * e);
+  w.ao = take(L * d->width * e);
+  w.y32 = (float*)take(L * d->width * 4);
+  w.h = take(L * d->inner * e);
+  w.pa = take(P * pd * e);        // encoder: gathered patches; decoder: proj_out output
+  w.pb = take(P * d->width * e);  // encoder: proj_in output;   decoder: ln_post output
+  w.total = off;
+  return w;
+}
+
+static int check_dims(const ttv_tower_dims* d, const ttv_batch* b) {
+  TTV_CHECK_ARG(d && b, "null dims/batch");
+  TTV_CHECK_ARG(d->dtype == TTV_BF16 || d->dtype == TTV_F32, "bad dtype %d", d->dtype);
+  TTV_CHECK_ARG(d->head_dim == 64 && d->width == d->q_heads * 64, "width must be q_heads*64");
+  TTV_CHECK_ARG(d->width % 64 == 0 && d->width <= 1024, "width %d unsupported", d->width);
+  TTV_CHECK_ARG(d->inner % 32 == 0, "GEGLU inner dim must be a multiple of 32");
+  TTV_CHECK_ARG(d->token_size >= 1 && d->token_size <= TTV_MAX_FSQ, "token_size out of range");
+  TTV_CHECK_ARG(((int64_t)d->pix_channels * d->patch_t * d->patch_h * d->patch_w) % 8 == 0, "patch vector length must be a multiple of 8");
+  TTV_CHECK_ARG(b->n_clips > 0 && b->total_rows == b->sum_tokens + b->sum_patches, "inconsistent batch");
+  return TTV_OK;
+}
+
+// One ResidualAttentionBlock stack (reference transformer.py:126-146) on ws.x in place.
+static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const TowerWs& ws, hipStream_t s) {
+  const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
+  const int nq = 2 * dm + 2 * g;
+  for (int i = 0; i < d->layers; ++i) {
+    const ttv_layer_weights& lw = w->layers[i];
+    // ---- attention sub-layer (transformer.py:85-104) ----
+    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+    GemmArgs a = {};
+    a.dtype = dt;
+    a.x = ws.xn; a.ldx = dm; a.w = lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+    a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+    TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
+    TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim, 1, dt, s));
+    GemmArgs o = {};
+    o.dtype = dt;
+    o.x = ws.ao; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
+    if (i == 0) {
+      o.alpha = 1.f; o.y = ws.x; o.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
+    } else {
+      o.alpha = d->alpha; o.y = ws.y32; o.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
+      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
+    }
+    // ---- GEGLU sub-layer (transformer.py:47-56) ----
+    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+    GemmArgs f = {};
+    f.dtype = dt;
+    f.x = ws.xn; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
+    TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
+    GemmArgs f3 = {};
+    f3.dtype = dt;
+    f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = L; f3.N = dm; f3.K = d->inner; f3.resid = ws.x; f3.ldr = dm;
+    if (i == 0) {
+      f3.alpha = 1.f; f3.y = ws.x; f3.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
+    } else {
+      f3.alpha = d->alpha; f3.y = ws.y32; f3.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
+      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s));
+    }
+  }
+  return TTV_OK;
+}
+
+extern "C" {
+
+const char* ttv_error_string(void) { return g_err; }
+int ttv_version(void) { return 100; }
+
+int ttv_fsq_forward(const ttv_fsq_params* p, const void* z, int z_dtype, int rows, void* codes, int codes_dtype, int32_t* indices,
+                    float* bounded, void* stream) {
+  TTV_CHECK_ARG(rows >= 0 && (rows == 0 || (z && codes && indices)), "fsq_forward: null buffer");
+  return ttvk_fsq_forward(p, z, z_dtype, rows, codes, codes_dtype, indices, bounded, (hipStream_t)stream);
+}
+
+int ttv_fsq_indices_to_codes(const ttv_fsq_params* p, const int32_t* indices, int rows, void* codes, int codes_dtype, void* stream) {
+  TTV_CHECK_ARG(rows >= 0 && (rows == 0 || (indices && codes)), "fsq_indices_to_codes: null buffer");
+  return ttvk_fsq_indices_to_codes(p, indices, rows, codes, codes_dtype, (hipStream_t)stream);
+}
+
+int ttv_rmsnorm(const void* in, int in_dtype, int ld_in, const int32_t* src_rows, void* out, int out_dtype, int ld_out,
+                const int32_t* dst_rows, const float* gain, int rows, int width, float eps, void* stream) {
+  TTV_CHECK_ARG(rows >= 0 && (rows == 0 || (in && out && gain)), "rmsnorm: null buffer");
+  return ttvk_rmsnorm(in, in_dtype, ld_in, src_rows, out, out_dtype, ld_out, dst_rows, gain, rows, width, eps, (hipStream_t)stream);
+}
+
+int ttv_rope_apply(void* x, int dtype, int ld, int rows, int heads, const float* rope_cs, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (x && rope_cs), "rope_apply: null buffer");
+  TTV_CHECK_ARG(ld % 4 == 0 && ld >= heads * 64, "rope_apply: bad leading dim");
+  return ttvk_rope_apply(x, dtype, ld, rows, heads, rope_cs, (hipStream_t)stream);
+}
+
+int ttv_linear(const void* x, int ldx, const void* w, int ldw, const void* bias, const float* add_scalar, void* y, int ldy, int M,
+               int N, int K, int dtype, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (x && w && y), "linear: null buffer");
+  GemmArgs a = {};
+  a.dtype = dtype; a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy;
+  a.bias = bias; a.add_scalar = add_scalar;
+  return ttvk_gemm(EPI_STORE, a, (hipStream_t)stream);
+}
+
+int ttv_linear_qkv_rope(const void* x, int ldx, const void* w, int ldw, void* y, int ldy, int M, int d_model, int gqa_dim,
+                        const float* rope_cs, int dtype, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (x && w && y && rope_cs), "linear_qkv_rope: null buffer");
+  GemmArgs a = {};
+  a.dtype = dtype; a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.M = M; a.N = 2 * d_model + 2 * gqa_dim; a.K = d_model;
+  a.y = y; a.ldy = ldy; a.rope_cs = rope_cs; a.rope_q_end = d_model; a.rope_k_begin = 2 * d_model; a.rope_k_end = 2 * d_model + gqa_dim;
+  return ttvk_gemm(EPI_QKV_ROPE, a, (hipStream_t)stream);
+}
+
+int ttv_linear_geglu(const void* x, int ldx, const void* w, int ldw, void* y, int ldy, int M, int I, int K, int dtype, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (x && w && y), "linear_geglu: null buffer");
+  GemmArgs a = {};
+  a.dtype = dtype; a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.M = M; a.N = I; a.K = K; a.y = y; a.ldy = ldy;
+  return ttvk_gemm(EPI_GEGLU, a, (hipStream_t)stream);
+}
+
+int ttv_linear_residual(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha, void* y, int ldy,
+                        int y_f32, int M, int N, int K, int dtype, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (x && w && y && resid), "linear_residual: null buffer");
+  GemmArgs a = {};
+  a.dtype = dtype; a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy;
+  a.resid = resid; a.ldr = ldr; a.alpha = alpha;
+  return ttvk_gemm(y_f32 ? EPI_RESID_F32 : EPI_RESID_T, a, (hipStream_t)stream);
+}
+
+int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
+                  int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream) {
+  TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention: null buffer");
+  return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, gate_mul, dtype, (hipStream_t)stream);
+}
+
+int ttv_patch_gather(const void* const* clips, const int32_t* clip_desc, int clip0, int n_clips, int patch_t, int patch_h, int patch_w,
+                     int channels, void* patches, int ld, int dtype, int max_patches_per_clip, void* stream) {
+  TTV_CHECK_ARG(n_clips == 0 || (clips && clip_desc && patches), "patch_gather: null buffer");
+  return ttvk_patch_copy(false, (void* const*)clips, clip_desc, clip0, n_clips, patch_t, patch_h, patch_w, channels, patches, ld, dtype, max_patches_per_clip, (hipStream_t)stream);
+}
+
+int ttv_patch_scatter(const void* patches, int ld, const int32_t* clip_desc, int clip0, int n_clips, int patch_t, int patch_h, int patch_w,
+                      int channels, void* const* clips, int dtype, int max_patches_per_clip, void* stream) {
+  TTV_CHECK_ARG(n_clips == 0 || (clips && clip_desc && patches), "patch_scatter: null buffer");
+  return ttvk_patch_copy(true, clips, clip_desc, clip0, n_clips, patch_t, patch_h, patch_w, channels, (void*)patches, ld, dtype, max_patches_per_clip, (hipStream_t)stream);
+}
+
+int64_t ttv_tower_workspace_bytes(const ttv_tower_dims* dims, const ttv_batch* batch) {
+  if (check_dims(dims, batch) != TTV_OK) return -1;
+  return carve(dims, batch, nullptr).total;
+}
+
+int ttv_encoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const void* const* clips,
+                        const ttv_fsq_params* fsq, float* z, void* codes, int32_t* indices, float* bounded, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
+  TTV_TRY(check_dims(d, b));
+  TTV_CHECK_ARG(d->kind == TTV_ENCODER, "encoder_forward: dims.kind is not TTV_ENCODER");
+  TTV_CHECK_ARG(w && w->layers && clips && workspace, "encoder_forward: null argument");
+  TTV_CHECK_ARG(fsq || z, "encoder_forward: neither fsq nor z requested");
+  TTV_CHECK_ARG(!fsq || (codes && indices), "encoder_forward: fsq needs codes and indices buffers");
+  hipStream_t s = (hipStream_t)stream;
+  TowerWs ws = carve(d, b, (char*)workspace);
+  TTV_CHECK_ARG(ws.total <= workspace_bytes, "encoder_forward: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)ws.total);
+  const int dm = d->width, dt = d->dtype, P = b->sum_patches;
+  const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+
+  // patchify (utils.py:26-34) + proj_in (blocks.py:91-93)
+  for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_patch_copy(false, (void* const*)(clips + c0), b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.pa, pd, dt, b->max_patches_per_clip, s));
+  }
+  GemmArgs a = {};
+  a.dtype = dt; a.x = ws.pa; a.ldx = pd; a.w = w->proj_in_w; a.ldw = pd; a.M = P; a.N = dm; a.K = pd; a.y = ws.pb; a.ldy = dm;
+  a.bias = w->proj_in_b; a.add_scalar = w->mask_token;
+  TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+  // x[patch rows] = ln_pre_p(patches + mask_token); x[latent rows] = ln_pre_t(mask_token * 1) (blocks.py:95-97)
+  TTV_TRY(ttvk_rmsnorm(ws.pb, dt, dm, nullptr, ws.x, dt, dm, b->patch_rows, w->ln_pre_p, P, dm, d->eps, s));
+  TTV_TRY(ttvk_fill_const_rows(ws.x, dt, dm, b->latent_rows, b->sum_tokens, dm, w->mask_token, w->ln_pre_t, d->eps, s));
+
+  TTV_TRY(run_layers(d, w, b, ws, s));
+
+  // tokens = proj_out(ln_post(x[latent rows])) -> FSQ (blocks.py:101-103, fsq.py:123-135)
+  TTV_TRY(ttvk_enc_tail(ws.x, dt, dm, b->latent_rows, b->sum_tokens, dm, w->ln_post, d->eps, w->proj_out_w, w->proj_out_b, d->token_size, fsq, z, codes, indices, bounded, s));
+  return TTV_OK;
+}
+
+int ttv_decoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const void* codes,
+                        void* const* clips_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTV_TRY(check_dims(d, b));
+  TTV_CHECK_ARG(d->kind == TTV_DECODER, "decoder_forward: dims.kind is not TTV_DECODER");
+  TTV_CHECK_ARG(w && w->layers && codes && clips_out && workspace, "decoder_forward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  TowerWs ws = carve(d, b, (char*)workspace);
+  TTV_CHECK_ARG(ws.total <= workspace_bytes, "decoder_forward: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)ws.total);
+  const int dm = d->width, dt = d->dtype, P = b->sum_patches;
+  const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+
+  // x[latent rows] = ln_pre_t(proj_in(codes) + mask_token); x[patch rows] = ln_pre_p(mask_token * 1) (blocks.py:165-167)
+  TTV_TRY(ttvk_dec_embed(codes, d->token_size, w->proj_in_w, w->proj_in_b, w->mask_token, w->ln_pre_t, ws.x, dt, dm, b->latent_rows, b->sum_tokens, dm, d->eps, s));
+  TTV_TRY(ttvk_fill_const_rows(ws.x, dt, dm, b->patch_rows, P, dm, w->mask_token, w->ln_pre_p, d->eps, s));
+
+  TTV_TRY(run_layers(d, w, b, ws, s));
+
+  // patches = proj_out(ln_post(x[patch rows])) -> unpatchify (blocks.py:171-176)
+  TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, b->patch_rows, ws.pb, dt, dm, nullptr, w->ln_post, P, dm, d->eps, s));
+  GemmArgs a = {};
+  a.dtype = dt; a.x = ws.pb; a.ldx = dm; a.w = w->proj_out_w; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.pa; a.ldy = pd;
+  a.bias = w->proj_out_b;
+  TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+  for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_patch_copy(true, clips_out + c0, b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.pa, pd, dt, b->max_patches_per_clip, s));
+  }
+  return TTV_OK;
+}
+
+int ttv_prof_begin(int kernel_class, int max_records) {
+  TTV_CHECK_ARG(g_ttv_prof_class == 0, "prof_begin: already recording");
+  TTV_CHECK_ARG(kernel_class > 0 && max_records > 0 && max_records <= (1 << 20), "prof_begin: bad arguments");
+  g_prof_start = new hipEvent_t[max_records];
+  g_prof_stop = new hipEvent_t[max_records];
+  for (int i = 0; i < max_records; ++i) {
+    if (hipEventCreate(&g_prof_start[i]) != hipSuccess || hipEventCreate(&g_prof_stop[i]) != hipSuccess) {
+      ttv_set_error("prof_begin: hipEventCreate failed");
+      return TTV_ERR_LAUNCH;
+    }
+  }
+  g_prof_cap = max_records;
+  g_prof_n = 0;
+  g_ttv_prof_class = kernel_class;
+  return TTV_OK;
+}
+
+int ttv_prof_end(double* total_ms, int* count) {
+  TTV_CHECK_ARG(g_ttv_prof_class != 0 && total_ms && count, "prof_end: not recording");
+  g_ttv_prof_class = 0;
+  double tot = 0.0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(g_prof_stop[i]);
+    (void)hipEventElapsedTime(&ms, g_prof_start[i], g_prof_stop[i]);
+    tot += ms;
+  }
+  *total_ms = tot;
+  *count = g_prof_n;
+  for (int i = 0; i < g_prof_cap; ++i) {
+    (void)hipEventDestroy(g_prof_start[i]);
+    (void)hipEventDestroy(g_prof_stop[i]);
+  }
+  delete[] g_prof_start;
+  delete[] g_prof_stop;
+  g_prof_start = g_prof_stop = nullptr;
+  g_prof_cap = g_prof_n = 0;
+  return TTV_OK;
+}
+
+int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int codebook_size, void* stream) {
+  TTV_CHECK_ARG(n == 0 || (indices && counts), "codebook_histogram: null buffer");
+  return ttvk_histogram(indices, n, counts, codebook_size, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,307 @@
+// Variable-length, non-causal GQA attention with the sigmoid output gate fused
+// (replaces flash_attn_varlen_func at reference model/base/transformer.py:100 and the gate at :103).
+//
+// bf16 kernel (head_dim 64).  One workgroup = 4 waves = 128 query rows of one (sequence, q-head); each wave owns
+// 32 queries.  K/V tiles of 64 keys are register-staged into double-buffered, XOR-swizzled LDS.
+//   S^T = K Q^T   : mfma_f32_32x32x16_bf16 with the KEY on the MFMA row and the QUERY on the lane (col = lane&31),
+//                   so a lane holds 32 scores of ONE query: row max / row sum are in-lane plus one xor-32 exchange.
+//   O^T = V^T P^T : the S^T accumulator registers, packed to bf16, ARE the B operand (k order
+//                   16s + 8(j>>2) + 4h + (j&3)); the matching V^T A operand is fetched with ds_read_b64_tr_b16
+//                   (hardware transpose read) straight from the row-major [key][d] LDS tile.
+// Online softmax in fp32 (exp2 with the scale folded into one FMA); output is normalised, multiplied by
+// sigmoid(gate) and stored as 4 consecutive head dims per lane.
+//
+// fp32 kernel: parity instrument (the reference never runs fp32 attention on GPU); one wave per query, 64 keys per step.
+#include "ttv_common.h"
+#include "ttv_kernels.h"
+
+#define QB 128
+#define KB 64
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements is returned column-major
+// (lane i of the group gets column i of the 4 rows).  EXEC must be all ones; addresses 8-byte aligned.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds_ptr));
+}
+
+template <bool GATE>
+__global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
+                                                      const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model,
+                                                      int gqa, int rep, float c_exp /* scale*log2(e) */) {
+  __shared__ __attribute__((aligned(16))) uint4 kl[2][KB * 8];
+  __shared__ __attribute__((aligned(16))) uint4 vl[2][KB * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int seq = qblocks[2 * blockIdx.x], q0 = qblocks[2 * blockIdx.x + 1];
+  const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int kvh = head / rep;
+  const bf16_t* qbase = qkvg + (size_t)s0 * ld + head * 64;
+  const bf16_t* gbase = qkvg + (size_t)s0 * ld + d_model + head * 64;
+  const bf16_t* kbase = qkvg + (size_t)s0 * ld + 2 * d_model + kvh * 64;
+  const bf16_t* vbase = kbase + gqa;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[query r][16*ks + 8h + 0..7]
+  const int qrow = q0 + wave * 32 + r;
+  const int qrc = qrow < S ? qrow : S - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8);
+
+  // staging assignment: 2 chunks (16 B) of K and 2 of V per thread per tile: key = (tid>>3) + 32*i, chunk = tid&7
+  const int skey = tid >> 3, scc = tid & 7;
+  const int kidx0 = skey * 8 + (scc ^ ((skey >> 1) & 7));
+  const int kidx1 = (skey + 32) * 8 + (scc ^ (((skey + 32) >> 1) & 7));
+  const int vidx0 = skey * 8 + (scc ^ (((skey >> 1) & 1) << 2));
+  const int vidx1 = (skey + 32) * 8 + (scc ^ ((((skey + 32) >> 1) & 1) << 2));
+  uint4 sk0, sk1, sv0, sv1;
+#define GLOAD(kt_)                                                                       \
+  do {                                                                                   \
+    int k0__ = (kt_) * KB + skey, k1__ = k0__ + 32;                                      \
+    k0__ = k0__ < S ? k0__ : S - 1;                                                      \
+    k1__ = k1__ < S ? k1__ : S - 1;                                                      \
+    sk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)k0__ * ld + scc * 8);          \
+    sk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)k1__ * ld + scc * 8);          \
+    sv0 = *reinterpret_cast<const uint4*>(vbase + (size_t)k0__ * ld + scc * 8);          \
+    sv1 = *reinterpret_cast<const uint4*>(vbase + (size_t)k1__ * ld + scc * 8);          \
+  } while (0)
+#define LSTORE(buf_)                                                                     \
+  do {                                                                                   \
+    kl[buf_][kidx0] = sk0; kl[buf_][kidx1] = sk1; vl[buf_][vidx0] = sv0; vl[buf_][vidx1] = sv1; \
+  } while (0)
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // transposed-read lane geometry (16-lane groups): lane 4q+p of a group addresses row q, columns 4p..4p+3
+  const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, g16 = (lane >> 4) & 1;
+
+  const int nkt = (S + KB - 1) / KB;
+  GLOAD(0);
+  LSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) GLOAD(kt + 1);
+
+    // ---- S^T = K Q^T (64 keys x 32 queries per wave) ----
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s_acc[t][e] = 0.f;
+      const int key = t * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = ks * 2 + h;
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, kl[buf][key * 8 + (chunk ^ ((key >> 1) & 7))]);
+        s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[t], 0, 0, 0);
+      }
+    }
+    // mask keys past the end of the sequence (last tile only)
+    if (kt * KB + KB > S) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * KB + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= S) s_acc[t][e] = -INFINITY;
+        }
+    }
+    // ---- online softmax (fp32) ----
+    float mx = s_acc[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s_acc[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+    const float mc = m_new * c_exp;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s_acc[t][e] = __builtin_amdgcn_exp2f(fmaf(s_acc[t][e], c_exp, -mc));
+        psum += s_acc[t][e];
+      }
+    // P as bf16 B-operand fragments: k-step (t, sp) = registers 8sp..8sp+7 of score tile t
+#define PFRAG(t_, sp_)                                                                                             \
+  ((bf16x8){(bf16_t)s_acc[t_][8 * sp_ + 0], (bf16_t)s_acc[t_][8 * sp_ + 1], (bf16_t)s_acc[t_][8 * sp_ + 2],        \
+            (bf16_t)s_acc[t_][8 * sp_ + 3], (bf16_t)s_acc[t_][8 * sp_ + 4], (bf16_t)s_acc[t_][8 * sp_ + 5],        \
+            (bf16_t)s_acc[t_][8 * sp_ + 6], (bf16_t)s_acc[t_][8 * sp_ + 7]})
+    const bf16x8 pf00 = PFRAG(0, 0), pf01 = PFRAG(0, 1), pf10 = PFRAG(1, 0), pf11 = PFRAG(1, 1);
+#undef PFRAG
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+    const char* vtile = reinterpret_cast<const char*>(&vl[buf][0]);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int chunk = dt * 4 + g16 * 2 + (tp >> 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const int row0 = t * 32 + sp * 16 + 4 * h + tq;
+          const int swz = ((row0 >> 1) & 1) << 2;  // same for row0 + 8
+          const int off0 = (row0 * 8 + (chunk ^ swz)) * 16 + (tp & 1) * 8;
+          const bf16x4 lo = lds_read_tr16(vtile + off0);
+          const bf16x4 hi = lds_read_tr16(vtile + off0 + 8 * 128);
+          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 pfr = t == 0 ? (sp == 0 ? pf00 : pf01) : (sp == 0 ? pf10 : pf11);
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfr, o_acc[dt], 0, 0, 0);
+        }
+    }
+
+    if (kt + 1 < nkt) LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef GLOAD
+#undef LSTORE
+
+  // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (qrow < S) {
+    bf16_t* orow = out + (size_t)(s0 + qrow) * ldo + head * 64;
+    const bf16_t* grow = gbase + (size_t)qrow * ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+        if (GATE) {
+          const f32x4 gt = Vec4<bf16_t>::load(grow + d0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= 1.0f / (1.0f + __expf(-gt[e]));
+        }
+        Vec4<bf16_t>::store(orow + d0, v);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 parity kernel: block = 4 waves, 128 queries; wave w walks queries w*32..w*32+31 one at a time,
+// lane j scores key j of the current 64-key tile, lane d accumulates output dim d.
+// ------------------------------------------------------------------------------------------------
+template <bool GATE>
+__global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
+                                                  const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
+                                                  int rep, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qs = smem;                    // [128][64]
+  float* ks = qs + QB * 64;            // [64][65]
+  float* vs = ks + KB * 65;            // [64][64]
+  float* ps = vs + KB * 64;            // [4][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.y;
+  const int seq = qblocks[2 * blockIdx.x], q0 = qblocks[2 * blockIdx.x + 1];
+  const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int kvh = head / rep;
+  const float* qbase = qkvg + (size_t)s0 * ld + head * 64;
+  const float* gbase = qkvg + (size_t)s0 * ld + d_model + head * 64;
+  const float* kbase = qkvg + (size_t)s0 * ld + 2 * d_model + kvh * 64;
+  const float* vbase = kbase + gqa;
+
+  for (int i = tid; i < QB * 64; i += 256) {
+    int row = q0 + (i >> 6);
+    row = row < S ? row : S - 1;
+    qs[i] = qbase[(size_t)row * ld + (i & 63)];
+  }
+  float m_run[32], l_run[32], o[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { m_run[i] = -INFINITY; l_run[i] = 0.f; o[i] = 0.f; }
+
+  const int nkt = (S + KB - 1) / KB;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    for (int i = tid; i < KB * 64; i += 256) {
+      int key = kt * KB + (i >> 6);
+      key = key < S ? key : S - 1;
+      ks[(i >> 6) * 65 + (i & 63)] = kbase[(size_t)key * ld + (i & 63)];
+      vs[i] = vbase[(size_t)key * ld + (i & 63)];
+    }
+    __syncthreads();
+    const bool valid = (kt * KB + lane) < S;
+#pragma unroll
+    for (int qi = 0; qi < 32; ++qi) {
+      const float* qv = qs + (wave * 32 + qi) * 64;
+      float sdot = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < 64; ++d) sdot = fmaf(qv[d], ks[lane * 65 + d], sdot);
+      sdot = valid ? sdot * scale : -INFINITY;
+      const float mx = wave_max(sdot);
+      const float m_new = fmaxf(m_run[qi], mx);
+      const float alpha = expf(m_run[qi] - m_new);
+      const float pj = expf(sdot - m_new);
+      l_run[qi] = l_run[qi] * alpha + wave_sum(pj);
+      m_run[qi] = m_new;
+      ps[wave * 64 + lane] = pj;
+      __builtin_amdgcn_wave_barrier();
+      float acc = o[qi] * alpha;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) acc = fmaf(ps[wave * 64 + j], vs[j * 64 + lane], acc);
+      o[qi] = acc;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < 32; ++qi) {
+    const int qrow = q0 + wave * 32 + qi;
+    if (qrow < S) {
+      float v = o[qi] / l_run[qi];
+      if (GATE) {
+        const float g = gbase[(size_t)qrow * ld + lane];
+        v *= 1.0f / (1.0f + expf(-g));
+      }
+      out[(size_t)(s0 + qrow) * ldo + head * 64 + lane] = v;
+    }
+  }
+}
+
+int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
+                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s) {
+  if (n_qblocks == 0) return TTV_OK;
+  TTV_CHECK_ARG(head_dim == 64, "attention: head_dim %d unsupported (the reference fixes 64, utils.py:8)", head_dim);
+  TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention: q_heads %% kv_heads");
+  const int d_model = q_heads * 64, gqa = kv_heads * 64, rep = q_heads / kv_heads;
+  TTV_CHECK_ARG(ld >= 2 * d_model + 2 * gqa && ld % 8 == 0 && ldo % 4 == 0, "attention: bad leading dims");
+  TTV_CHECK_ARG((uintptr_t)qkvg % 16 == 0 && (uintptr_t)out % 8 == 0, "attention: unaligned pointers");
+  dim3 grid(n_qblocks, q_heads);
+  const float scale = 0.125f;  // 64^-0.5
+  TtvProfScope prof(TTV_KC_ATTENTION, s);
+  if (dtype == TTV_BF16) {
+    const float c_exp = scale * 1.44269504088896340736f;
+    if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
+    else hipLaunchKernelGGL((k_attn_bf16<false>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
+  } else if (dtype == TTV_F32) {
+    const size_t smem = (QB * 64 + KB * 65 + KB * 64 + 4 * 64) * sizeof(float);
+    if (gate_mul) {
+      (void)hipFuncSetAttribute((const void*)k_attn_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_attn_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL((k_attn_f32<false>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale);
+    }
+  } else {
+    ttv_set_error("attention: bad dtype");
+    return TTV_ERR_INVALID;
+  }
+  TTV_CHECK_LAUNCH("attention");
+  return TTV_OK;
+}

@@ -1,0 +1,87 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/titok_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TTV_WAVE 64
+
+// ---- error plumbing (host) ------------------------------------------------------------------
+void ttv_set_error(const char* fmt, ...);
+#define TTV_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      ttv_set_error(__VA_ARGS__);         \
+      return TTV_ERR_INVALID;             \
+    }                                     \
+  } while (0)
+#define TTV_CHECK_LAUNCH(what)                                            \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) {                                              \
+      ttv_set_error("%s: %s", what, hipGetErrorString(e__));              \
+      return TTV_ERR_LAUNCH;                                              \
+    }                                                                     \
+  } while (0)
+
+// ---- storage <-> fp32 -----------------------------------------------------------------------
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  static __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
+};
+// round a fp32 value through the storage type (what a store+load of T would do)
+template <typename T> __device__ __forceinline__ float round_to(float v) { return Cvt<T>::to_f(Cvt<T>::from_f(v)); }
+
+// 4 consecutive elements
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+    bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 v = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    return v;
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
+    bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = b;
+  }
+};
+
+// ---- wave reductions (64 lanes, xor butterfly) ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- optional HIP-event bracketing of one kernel class (ttv_prof_begin / ttv_prof_end) ----------------
+extern int g_ttv_prof_class;
+struct TtvProfScope {
+  int slot;
+  hipStream_t s;
+  TtvProfScope(int cls, hipStream_t stream);
+  ~TtvProfScope();
+};
+
+static inline int ttv_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,441 @@
+// HBM-bound row kernels of the TiTok-Video path: RMSNorm, token/patch row initialisation, the encoder tail
+// (ln_post -> proj_out -> FSQ), FSQ, patch gather/scatter, rotary apply, codebook histogram.
+// One wave (64 lanes) owns one row; row statistics use xor-butterfly wave reductions; all loads are
+// 4-element vectors (8 B bf16 / 16 B fp32) per lane, consecutive lanes on consecutive addresses.
+#include "ttv_common.h"
+#include "ttv_kernels.h"
+
+#define ROWS_PER_BLOCK 4
+#define MAX_ITERS 4  // width <= 64 lanes * 4 elems * 4 iters = 1024
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm with optional row gather/scatter maps.
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int ld_in, const int* __restrict__ src_rows,
+                                                 TO* __restrict__ out, int ld_out, const int* __restrict__ dst_rows,
+                                                 const float* __restrict__ gain, int rows, int d, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  const int sr = src_rows ? src_rows[r] : r;
+  const int dr = dst_rows ? dst_rows[r] : r;
+  const TI* p = in + (size_t)sr * ld_in;
+  f32x4 v[MAX_ITERS];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < d) {
+      v[it] = Vec4<TI>::load(p + c);
+      ss += v[it][0] * v[it][0] + v[it][1] * v[it][1] + v[it][2] * v[it][2] + v[it][3] * v[it][3];
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+  TO* q = out + (size_t)dr * ld_out;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < d) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+      f32x4 o = {v[it][0] * rstd * g[0], v[it][1] * rstd * g[1], v[it][2] * rstd * g[2], v[it][3] * rstd * g[3]};
+      Vec4<TO>::store(q + c, o);
+    }
+  }
+}
+
+template <typename TI, typename TO>
+static int launch_rmsnorm(const void* in, int ld_in, const int* src_rows, void* out, int ld_out, const int* dst_rows,
+                          const float* gain, int rows, int d, float eps, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TtvProfScope prof(TTV_KC_RMSNORM, s);
+  hipLaunchKernelGGL((k_rmsnorm<TI, TO>), dim3(ttv_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, s, (const TI*)in, ld_in,
+                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps);
+  TTV_CHECK_LAUNCH("rmsnorm");
+  return TTV_OK;
+}
+
+int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s) {
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS, "rmsnorm: width %d must be a multiple of 4 and <= 1024", d);
+  TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "rmsnorm: leading dims must be multiples of 4");
+  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
+  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
+  ttv_set_error("rmsnorm: bad dtypes %d %d", in_dtype, out_dtype);
+  return TTV_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rows that hold RMSNorm(mask_token * ones(d)) * gain: encoder latent rows (blocks.py:96), decoder patch rows
+// (blocks.py:167).  Every such row is the same vector; mean(m^2) over a constant row is m^2.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_const_rows(T* __restrict__ x, int ld, const int* __restrict__ rows_map, int rows,
+                                                         int d, const float* __restrict__ mask_token,
+                                                         const float* __restrict__ gain, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  const float m = round_to<T>(mask_token[0]);  // mask_token.to(dtype)
+  const float rstd = 1.0f / sqrtf(m * m + eps);
+  T* q = x + (size_t)rows_map[r] * ld;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+    f32x4 o = {m * rstd * g[0], m * rstd * g[1], m * rstd * g[2], m * rstd * g[3]};
+    Vec4<T>::store(q + c, o);
+  }
+}
+
+int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* mask_token,
+                         const float* gain, float eps, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(d % 4 == 0, "fill_const_rows: width %% 4");
+  dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
+  if (dtype == TTV_BF16)
+    hipLaunchKernelGGL((k_fill_const_rows<bf16_t>), grid, dim3(256), 0, s, (bf16_t*)x, ld, rows_map, rows, d, mask_token, gain, eps);
+  else
+    hipLaunchKernelGGL((k_fill_const_rows<float>), grid, dim3(256), 0, s, (float*)x, ld, rows_map, rows, d, mask_token, gain, eps);
+  TTV_CHECK_LAUNCH("fill_const_rows");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder latent rows: RMSNorm_t(proj_in(codes) + bias + mask_token) (blocks.py:125,166).  K = token_size <= 8.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, int C, const T* __restrict__ w /*[d,C]*/,
+                                                   const T* __restrict__ bias, const float* __restrict__ mask_token,
+                                                   const float* __restrict__ gain, T* __restrict__ x, int ld,
+                                                   const int* __restrict__ rows_map, int rows, int d, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  float cz[TTV_MAX_FSQ];
+#pragma unroll
+  for (int c = 0; c < TTV_MAX_FSQ; ++c) cz[c] = c < C ? Cvt<T>::to_f(codes[(size_t)r * C + c]) : 0.f;
+  const float m = round_to<T>(mask_token[0]);
+  float v[MAX_ITERS][4];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = (it * 64 + lane) * 4 + e;
+      float h = 0.f;
+      if (f < d) {
+        for (int c = 0; c < C; ++c) h += cz[c] * Cvt<T>::to_f(w[(size_t)f * C + c]);
+        h = round_to<T>(h + Cvt<T>::to_f(bias[f]));  // nn.Linear output in dtype
+        h = round_to<T>(h + m);                      // + mask_token.to(dtype)
+      }
+      v[it][e] = h;
+      ss += h * h;
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+  T* q = x + (size_t)rows_map[r] * ld;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c0 = (it * 64 + lane) * 4;
+    if (c0 < d) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c0);
+      f32x4 o = {v[it][0] * rstd * g[0], v[it][1] * rstd * g[1], v[it][2] * rstd * g[2], v[it][3] * rstd * g[3]};
+      Vec4<T>::store(q + c0, o);
+    }
+  }
+}
+
+int ttvk_dec_embed(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain,
+                   void* x, int dtype, int ld, const int* rows_map, int rows, int d, float eps, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_FSQ, "dec_embed: token_size %d out of range", C);
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "dec_embed: width");
+  dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
+  if (dtype == TTV_BF16)
+    hipLaunchKernelGGL((k_dec_embed<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)codes, C, (const bf16_t*)w, (const bf16_t*)bias, mask_token, gain, (bf16_t*)x, ld, rows_map, rows, d, eps);
+  else
+    hipLaunchKernelGGL((k_dec_embed<float>), grid, dim3(256), 0, s, (const float*)codes, C, (const float*)w, (const float*)bias, mask_token, gain, (float*)x, ld, rows_map, rows, d, eps);
+  TTV_CHECK_LAUNCH("dec_embed");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FSQ (fsq.py:78-135).  The arithmetic is written op by op (no FMA contraction) so that it follows the
+// reference's sequence of fp32 tensor ops: tanh(z+shift)*half_l-offset -> round-half-even -> /half_width ->
+// *half_width+half_width -> *basis -> sum -> int32 truncation.
+// ------------------------------------------------------------------------------------------------
+struct FsqDev {
+  int n;
+  float half_l[TTV_MAX_FSQ], offset[TTV_MAX_FSQ], shift[TTV_MAX_FSQ], half_width[TTV_MAX_FSQ], basis[TTV_MAX_FSQ];
+  int levels[TTV_MAX_FSQ], ibasis[TTV_MAX_FSQ];
+};
+
+static FsqDev to_dev(const ttv_fsq_params* p) {
+  FsqDev d;
+  d.n = p->n;
+  for (int i = 0; i < TTV_MAX_FSQ; ++i) {
+    d.half_l[i] = p->half_l[i]; d.offset[i] = p->offset[i]; d.shift[i] = p->shift[i];
+    d.half_width[i] = p->half_width[i]; d.basis[i] = (float)p->basis[i];
+    d.levels[i] = p->levels[i]; d.ibasis[i] = p->basis[i];
+  }
+  return d;
+}
+
+__device__ __forceinline__ float fsq_channel(const FsqDev& p, int c, float z, float* bounded_out, float* code_out) {
+  const float b = __fsub_rn(__fmul_rn(tanhf(__fadd_rn(z, p.shift[c])), p.half_l[c]), p.offset[c]);
+  const float q = rintf(b);                       // round half to even, like torch.round
+  const float code = __fdiv_rn(q, p.half_width[c]);
+  const float zhat = __fadd_rn(__fmul_rn(code, p.half_width[c]), p.half_width[c]);
+  *bounded_out = b;
+  *code_out = code;
+  return __fmul_rn(zhat, p.basis[c]);
+}
+
+template <typename TZ, typename TC>
+__global__ __launch_bounds__(256) void k_fsq_forward(FsqDev p, const TZ* __restrict__ z, int rows, TC* __restrict__ codes,
+                                                     int* __restrict__ indices, float* __restrict__ bounded) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float acc = 0.f;
+  for (int c = 0; c < p.n; ++c) {
+    float b, code;
+    acc = __fadd_rn(acc, fsq_channel(p, c, Cvt<TZ>::to_f(z[(size_t)r * p.n + c]), &b, &code));
+    codes[(size_t)r * p.n + c] = Cvt<TC>::from_f(code);
+    if (bounded) bounded[(size_t)r * p.n + c] = b;
+  }
+  indices[r] = (int)acc;
+}
+
+int ttvk_fsq_forward(const ttv_fsq_params* p, const void* z, int z_dtype, int rows, void* codes, int codes_dtype, int* indices,
+                     float* bounded, hipStream_t s) {
+  TTV_CHECK_ARG(p && p->n >= 1 && p->n <= TTV_MAX_FSQ, "fsq: codebook_dim out of range");
+  if (rows == 0) return TTV_OK;
+  FsqDev d = to_dev(p);
+  dim3 grid(ttv_cdiv(rows, 256));
+  if (z_dtype == TTV_F32 && codes_dtype == TTV_F32)
+    hipLaunchKernelGGL((k_fsq_forward<float, float>), grid, dim3(256), 0, s, d, (const float*)z, rows, (float*)codes, indices, bounded);
+  else if (z_dtype == TTV_F32 && codes_dtype == TTV_BF16)
+    hipLaunchKernelGGL((k_fsq_forward<float, bf16_t>), grid, dim3(256), 0, s, d, (const float*)z, rows, (bf16_t*)codes, indices, bounded);
+  else if (z_dtype == TTV_BF16 && codes_dtype == TTV_BF16)
+    hipLaunchKernelGGL((k_fsq_forward<bf16_t, bf16_t>), grid, dim3(256), 0, s, d, (const bf16_t*)z, rows, (bf16_t*)codes, indices, bounded);
+  else if (z_dtype == TTV_BF16 && codes_dtype == TTV_F32)
+    hipLaunchKernelGGL((k_fsq_forward<bf16_t, float>), grid, dim3(256), 0, s, d, (const bf16_t*)z, rows, (float*)codes, indices, bounded);
+  else { ttv_set_error("fsq: bad dtypes"); return TTV_ERR_INVALID; }
+  TTV_CHECK_LAUNCH("fsq_forward");
+  return TTV_OK;
+}
+
+template <typename TC>
+__global__ __launch_bounds__(256) void k_fsq_indices_to_codes(FsqDev p, const int* __restrict__ indices, int rows,
+                                                              TC* __restrict__ codes) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int idx = indices[r];
+  for (int c = 0; c < p.n; ++c) {
+    const int lvl = (idx / p.ibasis[c]) % p.levels[c];            // fsq.py:111-115
+    const float hw = p.half_width[c];
+    codes[(size_t)r * p.n + c] = Cvt<TC>::from_f(__fdiv_rn(__fsub_rn((float)lvl, hw), hw));  // fsq.py:96-98
+  }
+}
+
+int ttvk_fsq_indices_to_codes(const ttv_fsq_params* p, const int* indices, int rows, void* codes, int codes_dtype, hipStream_t s) {
+  TTV_CHECK_ARG(p && p->n >= 1 && p->n <= TTV_MAX_FSQ, "fsq: codebook_dim out of range");
+  if (rows == 0) return TTV_OK;
+  FsqDev d = to_dev(p);
+  dim3 grid(ttv_cdiv(rows, 256));
+  if (codes_dtype == TTV_F32) hipLaunchKernelGGL((k_fsq_indices_to_codes<float>), grid, dim3(256), 0, s, d, indices, rows, (float*)codes);
+  else hipLaunchKernelGGL((k_fsq_indices_to_codes<bf16_t>), grid, dim3(256), 0, s, d, indices, rows, (bf16_t*)codes);
+  TTV_CHECK_LAUNCH("fsq_indices_to_codes");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder tail (blocks.py:101-103 + fsq.py:123-135): gather latent rows -> ln_post -> proj_out (d -> C) + bias -> FSQ.
+// One wave per latent token; the C <= 8 dot products are wave reductions; z stays fp32 into the quantiser.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_tail(const T* __restrict__ x, int ld, const int* __restrict__ rows_map, int rows,
+                                                  int d, const float* __restrict__ gain, float eps,
+                                                  const T* __restrict__ w /*[C,d]*/, const T* __restrict__ bias, int C,
+                                                  FsqDev p, int have_fsq, float* __restrict__ z_out, T* __restrict__ codes,
+                                                  int* __restrict__ indices, float* __restrict__ bounded) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  const T* px = x + (size_t)rows_map[r] * ld;
+  f32x4 v[MAX_ITERS];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < d) {
+      v[it] = Vec4<T>::load(px + c);
+      ss += v[it][0] * v[it][0] + v[it][1] * v[it][1] + v[it][2] * v[it][2] + v[it][3] * v[it][3];
+    } else {
+      v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < d) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[it][e] = round_to<T>(v[it][e] * rstd * g[e]);  // ln_post output in dtype
+    }
+  }
+  float zc[TTV_MAX_FSQ];
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_ITERS; ++it) {
+      const int f = (it * 64 + lane) * 4;
+      if (f < d) {
+        const f32x4 wv = Vec4<T>::load(w + (size_t)c * d + f);
+        acc += v[it][0] * wv[0] + v[it][1] * wv[1] + v[it][2] * wv[2] + v[it][3] * wv[3];
+      }
+    }
+    zc[c] = wave_sum(acc) + Cvt<T>::to_f(bias[c]);
+  }
+  if (lane == 0) {
+    float idx = 0.f;
+    for (int c = 0; c < C; ++c) {
+      if (z_out) z_out[(size_t)r * C + c] = zc[c];
+      if (have_fsq) {
+        float b, code;
+        idx = __fadd_rn(idx, fsq_channel(p, c, zc[c], &b, &code));
+        codes[(size_t)r * C + c] = Cvt<T>::from_f(code);
+        if (bounded) bounded[(size_t)r * C + c] = b;
+      }
+    }
+    if (have_fsq) indices[r] = (int)idx;
+  }
+}
+
+int ttvk_enc_tail(const void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* gain, float eps,
+                  const void* w, const void* bias, int C, const ttv_fsq_params* fsq, float* z_out, void* codes, int* indices,
+                  float* bounded, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_FSQ, "enc_tail: token_size %d out of range", C);
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "enc_tail: width");
+  TTV_CHECK_ARG(!fsq || fsq->n == C, "enc_tail: fsq dim != token_size");
+  FsqDev p;
+  if (fsq) p = to_dev(fsq); else { p = FsqDev(); p.n = 0; }
+  dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
+  if (dtype == TTV_BF16)
+    hipLaunchKernelGGL((k_enc_tail<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ld, rows_map, rows, d, gain, eps, (const bf16_t*)w, (const bf16_t*)bias, C, p, fsq ? 1 : 0, z_out, (bf16_t*)codes, indices, bounded);
+  else
+    hipLaunchKernelGGL((k_enc_tail<float>), grid, dim3(256), 0, s, (const float*)x, ld, rows_map, rows, d, gain, eps, (const float*)w, (const float*)bias, C, p, fsq ? 1 : 0, z_out, (float*)codes, indices, bounded);
+  TTV_CHECK_LAUNCH("enc_tail");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch gather / scatter (utils.py:26-51).  A segment = the pw contiguous pixels of one (c, ipt, iph) image row
+// of a patch; the patch vector is stored in (c,pt,ph,pw) order so a segment is one 16-byte vector for pw = 8 bf16.
+// ------------------------------------------------------------------------------------------------
+struct ClipPtrs { void* p[TTV_MAX_CLIPS_PER_LAUNCH]; };
+
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void k_patch_copy(ClipPtrs clips, const int* __restrict__ clip_desc, int clip0, int pt, int ph,
+                                                    int pw, int C, T* __restrict__ patches, int ld) {
+  const int* ds = clip_desc + (size_t)(clip0 + blockIdx.y) * 8;
+  const int Tn = ds[0], H = ds[1], W = ds[2], gh = ds[4], gw = ds[5], base = ds[6];
+  const int P = ds[3] * gh * gw;
+  const int nseg = C * pt * ph;
+  const int total = P * nseg;
+  T* clip = reinterpret_cast<T*>(clips.p[blockIdx.y]);
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int p = idx / nseg, sg = idx - p * nseg;
+    const int c = sg / (pt * ph), ipt = (sg / ph) % pt, iph = sg % ph;
+    const int gwi = p % gw, ghi = (p / gw) % gh, gti = p / (gw * gh);
+    T* src = clip + (((size_t)c * Tn + gti * pt + ipt) * H + ghi * ph + iph) * W + gwi * pw;
+    T* dst = patches + (size_t)(base + p) * ld + sg * pw;
+    if ((pw * sizeof(T)) % 16 == 0) {
+      for (int e = 0; e < (int)(pw * sizeof(T) / 16); ++e) {
+        if (SCATTER) reinterpret_cast<uint4*>(src)[e] = reinterpret_cast<const uint4*>(dst)[e];
+        else reinterpret_cast<uint4*>(dst)[e] = reinterpret_cast<const uint4*>(src)[e];
+      }
+    } else {
+      for (int e = 0; e < pw; ++e) {
+        if (SCATTER) src[e] = dst[e]; else dst[e] = src[e];
+      }
+    }
+  }
+}
+
+int ttvk_patch_copy(bool scatter, void* const* clips, const int* clip_desc, int clip0, int n_clips, int pt, int ph, int pw,
+                    int C, void* patches, int ld, int dtype, int max_patches, hipStream_t s) {
+  TTV_CHECK_ARG(n_clips >= 0 && n_clips <= TTV_MAX_CLIPS_PER_LAUNCH, "patch_copy: at most %d clips per call", TTV_MAX_CLIPS_PER_LAUNCH);
+  if (n_clips == 0 || max_patches == 0) return TTV_OK;
+  ClipPtrs cp;
+  for (int i = 0; i < n_clips; ++i) cp.p[i] = clips[i];
+  TtvProfScope prof(TTV_KC_PATCH, s);
+  const int total = max_patches * C * pt * ph;
+  dim3 grid(ttv_cdiv(total, 256) > 4096 ? 4096 : ttv_cdiv(total, 256), n_clips);
+  if (dtype == TTV_BF16) {
+    if (scatter) hipLaunchKernelGGL((k_patch_copy<bf16_t, true>), grid, dim3(256), 0, s, cp, clip_desc, clip0, pt, ph, pw, C, (bf16_t*)patches, ld);
+    else hipLaunchKernelGGL((k_patch_copy<bf16_t, false>), grid, dim3(256), 0, s, cp, clip_desc, clip0, pt, ph, pw, C, (bf16_t*)patches, ld);
+  } else {
+    if (scatter) hipLaunchKernelGGL((k_patch_copy<float, true>), grid, dim3(256), 0, s, cp, clip_desc, clip0, pt, ph, pw, C, (float*)patches, ld);
+    else hipLaunchKernelGGL((k_patch_copy<float, false>), grid, dim3(256), 0, s, cp, clip_desc, clip0, pt, ph, pw, C, (float*)patches, ld);
+  }
+  TTV_CHECK_LAUNCH("patch_copy");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rotary apply, standalone (rope.py:19-27).  The tower path fuses this into the QKV GEMM epilogue.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_rope_apply(T* __restrict__ x, int ld, int rows, int heads,
+                                                    const float* __restrict__ cs) {
+  // thread -> (row, head, 4 consecutive dims = 2 complex pairs)
+  const long total = (long)rows * heads * 16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q4 = (int)(i % 16), h = (int)((i / 16) % heads);
+    const long r = i / (16 * heads);
+    T* p = x + r * ld + h * 64 + q4 * 4;
+    const float* c = cs + r * 64 + q4 * 2;
+    f32x4 v = Vec4<T>::load(p);
+    const float c0 = c[0], c1 = c[1], s0 = c[32], s1 = c[33];
+    f32x4 o = {v[0] * c0 - v[1] * s0, v[0] * s0 + v[1] * c0, v[2] * c1 - v[3] * s1, v[2] * s1 + v[3] * c1};
+    Vec4<T>::store(p, o);
+  }
+}
+
+int ttvk_rope_apply(void* x, int dtype, int ld, int rows, int heads, const float* cs, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  const long total = (long)rows * heads * 16;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_rope_apply<bf16_t>), dim3(blocks), dim3(256), 0, s, (bf16_t*)x, ld, rows, heads, cs);
+  else hipLaunchKernelGGL((k_rope_apply<float>), dim3(blocks), dim3(256), 0, s, (float*)x, ld, rows, heads, cs);
+  TTV_CHECK_LAUNCH("rope_apply");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Codebook usage histogram (codebook_logging.py:19-25: sum of bincounts).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_histogram(const int* __restrict__ idx, int n, unsigned long long* __restrict__ counts,
+                                                   int size) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int v = idx[i];
+    if (v >= 0 && v < size) atomicAdd(&counts[v], 1ULL);
+  }
+}
+
+int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t s) {
+  if (n == 0) return TTV_OK;
+  int blocks = ttv_cdiv(n, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_histogram, dim3(blocks), dim3(256), 0, s, idx, n, (unsigned long long*)counts, size);
+  TTV_CHECK_LAUNCH("histogram");
+  return TTV_OK;
+}

@@ -1,0 +1,54 @@
+// Internal launch functions (host side).  The C-ABI in include/titok_hip.h is layered on these.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/titok_hip.h"
+
+// ---- ttv_elem.hip ----
+int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s);
+int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* mask_token,
+                         const float* gain, float eps, hipStream_t s);
+int ttvk_dec_embed(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain,
+                   void* x, int dtype, int ld, const int* rows_map, int rows, int d, float eps, hipStream_t s);
+int ttvk_fsq_forward(const ttv_fsq_params* p, const void* z, int z_dtype, int rows, void* codes, int codes_dtype, int* indices,
+                     float* bounded, hipStream_t s);
+int ttvk_fsq_indices_to_codes(const ttv_fsq_params* p, const int* indices, int rows, void* codes, int codes_dtype, hipStream_t s);
+int ttvk_enc_tail(const void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* gain, float eps,
+                  const void* w, const void* bias, int C, const ttv_fsq_params* fsq, float* z_out, void* codes, int* indices,
+                  float* bounded, hipStream_t s);
+int ttvk_patch_copy(bool scatter, void* const* clips, const int* clip_desc, int clip0, int n_clips, int pt, int ph, int pw,
+                    int C, void* patches, int ld, int dtype, int max_patches, hipStream_t s);
+int ttvk_rope_apply(void* x, int dtype, int ld, int rows, int heads, const float* cs, hipStream_t s);
+int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t s);
+
+// ---- ttv_gemm.hip ----
+// out^T-oriented GEMM: the MFMA "row" side is the output feature (W rows), the "column" side the token (X rows),
+// so every lane owns 4 consecutive output features of one token and the epilogues below are lane-local.
+enum GemmEpilogue {
+  EPI_STORE = 0,   // y = acc (+bias) (+*add_scalar), stored in dtype
+  EPI_QKV_ROPE,    // y = acc with rotary applied to the q and k column ranges (transformer.py:87,97-98)
+  EPI_GEGLU,       // y[:, f] = gelu(acc[:, I+f]) * acc[:, f]           (transformer.py:51-52)
+  EPI_RESID_T,     // y = alpha*resid + acc, stored in dtype            (layer 0 residual, transformer.py:129-130)
+  EPI_RESID_F32,   // y = alpha*resid + acc, stored fp32                (KEEL pre-post-norm sum, transformer.py:141,144)
+};
+
+struct GemmArgs {
+  const void* x; int ldx;          // tokens  [M,K]
+  const void* w; int ldw;          // weights [N,K]  (EPI_GEGLU: [2I,K], N = I)
+  int M, N, K;
+  void* y; int ldy;
+  const void* bias;                // [N] dtype or null
+  const float* add_scalar;         // device scalar or null
+  const void* resid; int ldr;      // [M,N] dtype
+  float alpha;
+  const float* rope_cs;            // [M,64]
+  int rope_q_end, rope_k_begin, rope_k_end;  // column ranges [0,q_end) and [k_begin,k_end) get rotary
+  int dtype;
+};
+int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+
+// ---- ttv_attn.hip ----
+int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
+                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s);
