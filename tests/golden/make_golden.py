@@ -181,6 +181,23 @@ def main():
               f"min margin {margin.min():.2e}, recon std {torch.cat([r.flatten() for r in recon]).std():.3f}")
         return clips, z, codes, d["indices"], bounded, recon
 
+    model_bf16 = TiTok(ref_config(levels)).eval()
+    model_bf16.load_state_dict(sd, strict=True)
+    model_bf16 = model_bf16.to(torch.bfloat16)
+
+    def run_bf16(shapes, counts, seed, ref_codes):
+        """The reference's own modules in bf16 (its real configuration is bf16 on GPU): how far ITS bf16 run is from
+        its fp32 run on the same inputs - the yardstick for the HIP bf16 path."""
+        clips = synthetic_clips(shapes, seed=seed, dtype=torch.bfloat16)
+        tc = torch.tensor(counts, dtype=torch.int32)
+        with torch.no_grad():
+            grids = torch.tensor([c.shape[1:] for c in clips], dtype=torch.int32)
+            z = model_bf16.encoder(clips, tc, grids)
+            _, d = model_bf16.quantize(z)
+            bounded = model_bf16.quantize.bound(z.float())
+            recon = model_bf16.decode(ref_codes.to(torch.bfloat16), tc, grids)   # decoder on the fp32 run's codes
+        return d["indices"], bounded, recon
+
     # small mixed-shape batch: full tensors
     shapes = [(4, 16, 16), (8, 32, 48), (4, 8, 24), (8, 16, 16)]
     counts = [1, 5, 3, 8]
@@ -190,6 +207,10 @@ def main():
              "z": np32(z), "codes": np32(codes), "indices": idx.numpy(), "bounded": np32(bounded)}
     for i, r in enumerate(recon):
         small[f"recon_{i}"] = np32(r)
+    i16, b16, r16 = run_bf16(shapes, counts, 77, codes)
+    small["indices_refbf16"], small["bounded_refbf16"] = i16.numpy(), np32(b16)
+    for i, r in enumerate(r16):
+        small[f"recon_refbf16_{i}"] = np32(r)
     save("titok_small.npz", **small)
 
     # packing invariance material: clip 1 alone
@@ -204,7 +225,9 @@ def main():
     clips, z, codes, idx, bounded, recon = run(shapes, counts, seed=1234)
     rs = torch.stack(recon)                       # [4,3,16,128,128]
     sample = rs[:, :, ::4, ::8, ::8].contiguous()   # [4,3,4,16,16]
-    save("titok_cfg1.npz", shapes=np.array(shapes, dtype=np.int32), counts=np.array(counts, dtype=np.int32),
+    i16, b16, r16 = run_bf16(shapes, counts, 1234, codes)
+    sample16 = torch.stack(r16)[:, :, ::4, ::8, ::8].contiguous()
+    save("titok_cfg1.npz", indices_refbf16=i16.numpy(), bounded_refbf16=np32(b16), recon_sample_refbf16=np32(sample16), shapes=np.array(shapes, dtype=np.int32), counts=np.array(counts, dtype=np.int32),
          clip_seed=np.int32(1234), weight_seed=np.int32(0), levels=np.array(levels, dtype=np.int32),
          z=np32(z), indices=idx.numpy(), bounded=np32(bounded), recon_sample=np32(sample),
          recon_mean=np.float64(rs.double().mean().item()), recon_std=np.float64(rs.double().std().item()),
