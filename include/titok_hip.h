@@ -130,6 +130,10 @@ typedef struct ttv_layer_weights {
   const void* w3;             /* ffd_layer.i.w3.weight [d, I]              */
   const float* attn_post_ln;  /* attn_post_ln.(i-1).weight, NULL for i==0  */
   const float* ffd_post_ln;   /* ffd_post_ln.(i-1).weight, NULL for i==0   */
+  /* optional (bf16, width 256): to_qkv / w12 with the preceding RMSNorm gain folded into the columns
+   * (w * gain[None,:]); when non-NULL the pre-norm runs inside the GEMM (rstd from the register-resident row) */
+  const void* to_qkv_pn;
+  const void* w12_pn;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {

@@ -36,7 +36,7 @@ class TowerDims(C.Structure):
 
 class LayerWeights(C.Structure):
     _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
-                ("attn_post_ln", vp), ("ffd_post_ln", vp)]
+                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp)]
 
 
 class TowerWeights(C.Structure):

@@ -86,10 +86,12 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
     // ---- attention sub-layer (transformer.py:85-104) ----
-    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+    const bool fold_qkv = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn;
+    if (!fold_qkv) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
     GemmArgs a = {};
     a.dtype = dt;
-    a.x = ws.xn; a.ldx = dm; a.w = lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+    a.prenorm = fold_qkv; a.eps = d->eps;
+    a.x = fold_qkv ? ws.x : ws.xn; a.ldx = dm; a.w = fold_qkv ? lw.to_qkv_pn : lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
     a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
     TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim, 1, dt, s));
@@ -105,10 +107,12 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
-    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+    const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
+    if (!fold_ffd) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
     f.dtype = dt;
-    f.x = ws.xn; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
+    f.prenorm = fold_ffd; f.eps = d->eps;
+    f.x = fold_ffd ? ws.x : ws.xn; f.ldx = dm; f.w = fold_ffd ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
     TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
     GemmArgs f3 = {};
     f3.dtype = dt;

@@ -21,6 +21,7 @@ struct GemmDev {
   int w_rows;  // rows of w that may be read (N, or 2I for GEGLU)
   float alpha;
   int rope_q_end, rope_k_begin, rope_k_end;
+  float eps;  // RMSNorm eps for the folded pre-norm (k256 kernel)
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -197,6 +198,142 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
 }
 
 // ================================================================================================
+// bf16 MFMA kernel for K == 256 (every to_qkv / w12 / out_proj / decoder proj_out of a width-256 tower)
+//
+// With K this short a classic tiled GEMM spends its time in per-tile load latency, so this kernel keeps the TOKEN
+// operand in registers for the whole K (a wave owns 64 tokens: 4 n-tiles x 8 k-steps x 16 B = 128 VGPRs) and streams
+// 64-row WEIGHT panels (32 KiB) through double-buffered LDS.  Blocks are persistent over a contiguous range of
+// (token tile, panel) items, so the token registers are loaded once per 128-token tile and the steady state is
+// {prefetch next panel -> 64 MFMA per wave from LDS -> epilogue -> stage -> one barrier}.
+//
+// PRENORM: the preceding RMSNorm (transformer.py:86 / :48) is folded in: its gain is pre-multiplied into the weight
+// columns on the host (w' = w * gain), and rstd = rsqrt(mean(x^2)+eps) is computed here from the register-resident
+// token row (in-lane sum + two xor shuffles) and applied to the fp32 accumulator - x_normed is never materialised.
+// ================================================================================================
+#define K256_TT 128
+#define K256_ROWS 64
+
+template <int EPI, bool PRENORM>
+__global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, int total_items) {
+  constexpr bool DUAL = (EPI == EPI_GEGLU);
+  constexpr int FO = DUAL ? 32 : 64;  // output features per panel
+  __shared__ uint4 wl[2][K256_ROWS * 32];  // [buffer][row*32 + swizzled 16-byte chunk], 2 x 32 KiB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wf = wave & 1, wt = wave >> 1;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int it0 = (int)((long)total_items * blockIdx.x / gridDim.x);
+  const int it1 = (int)((long)total_items * (blockIdx.x + 1) / gridDim.x);
+  if (it0 >= it1) return;
+
+  const bf16_t* W = (const bf16_t*)p.w;
+  const bf16_t* X = (const bf16_t*)p.x;
+
+  // staging: 8 chunks per thread per panel; chunk = tid + 256*i -> row = (tid>>5) + 8*i, ch = tid & 31
+  const int srow = tid >> 5, sch = tid & 31;
+  uint4 st0, st1, st2, st3, st4, st5, st6, st7;
+#define WROW(panel_, i_)                                                                                     \
+  ({                                                                                                         \
+    const int row__ = srow + 8 * (i_);                                                                       \
+    int wr__ = DUAL ? (row__ < 32 ? (panel_) * 32 + row__ : p.N + (panel_) * 32 + (row__ - 32)) : (panel_) * 64 + row__; \
+    wr__ = wr__ < p.w_rows ? wr__ : p.w_rows - 1;                                                            \
+    *reinterpret_cast<const uint4*>(W + (size_t)wr__ * p.ldw + sch * 8);                                     \
+  })
+#define GLOADP(panel_)                                                                                       \
+  do {                                                                                                       \
+    st0 = WROW(panel_, 0); st1 = WROW(panel_, 1); st2 = WROW(panel_, 2); st3 = WROW(panel_, 3);              \
+    st4 = WROW(panel_, 4); st5 = WROW(panel_, 5); st6 = WROW(panel_, 6); st7 = WROW(panel_, 7);              \
+  } while (0)
+#define LIDX(i_) ((srow + 8 * (i_)) * 32 + ((sch & 16) | ((sch & 15) ^ ((srow + 8 * (i_)) & 15))))
+#define LSTOREP(buf_)                                                                                        \
+  do {                                                                                                       \
+    wl[buf_][LIDX(0)] = st0; wl[buf_][LIDX(1)] = st1; wl[buf_][LIDX(2)] = st2; wl[buf_][LIDX(3)] = st3;      \
+    wl[buf_][LIDX(4)] = st4; wl[buf_][LIDX(5)] = st5; wl[buf_][LIDX(6)] = st6; wl[buf_][LIDX(7)] = st7;      \
+  } while (0)
+
+  // A-fragment rows of this wave inside a panel
+  const int arow0 = (DUAL ? wf * 16 : wf * 32) + l15;
+  const int arow1 = (DUAL ? 32 + wf * 16 : wf * 32 + 16) + l15;
+
+  bf16x8 bfr[4][8];
+  float rstd[4] = {1.f, 1.f, 1.f, 1.f};
+  int cur_tile = -1;
+
+  GLOADP(it0 % n_panels);
+  LSTOREP(0);
+  __syncthreads();
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    const int tile = it / n_panels, panel = it - tile * n_panels;
+    if (tile != cur_tile) {
+      cur_tile = tile;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int t = tile * K256_TT + wt * 64 + j * 16 + l15;
+        t = t < p.M ? t : p.M - 1;
+        const bf16_t* xr = X + (size_t)t * p.ldx + kq * 8;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
+      }
+      if (PRENORM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float ss = 0.f;
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = (float)bfr[j][s8][e];
+              ss = fmaf(v, v, ss);
+            }
+          ss += __shfl_xor(ss, 16, 64);
+          ss += __shfl_xor(ss, 32, 64);
+          rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+        }
+      }
+    }
+    if (it + 1 < it1) GLOADP((it + 1) % n_panels);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int ch = s8 * 4 + kq;
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, wl[buf][arow0 * 32 + ((ch & 16) | ((ch & 15) ^ (arow0 & 15)))]);
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, wl[buf][arow1 * 32 + ((ch & 16) | ((ch & 15) ^ (arow1 & 15)))]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[j][s8], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[j][s8], acc[1][j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = tile * K256_TT + wt * 64 + j * 16 + l15;
+      if (PRENORM) {
+        acc[0][j] *= rstd[j];
+        acc[1][j] *= rstd[j];
+      }
+      if (DUAL) {
+        epilogue<EPI, bf16_t>(p, t, panel * FO + wf * 16 + kq * 4, acc[0][j], acc[1][j]);
+      } else {
+        epilogue<EPI, bf16_t>(p, t, panel * FO + wf * 32 + kq * 4, acc[0][j], acc[0][j]);
+        epilogue<EPI, bf16_t>(p, t, panel * FO + wf * 32 + 16 + kq * 4, acc[1][j], acc[1][j]);
+      }
+    }
+    if (it + 1 < it1) LSTOREP(buf ^ 1);
+    __syncthreads();
+  }
+#undef WROW
+#undef GLOADP
+#undef LIDX
+#undef LSTOREP
+}
+
+// ================================================================================================
 // fp32 kernel (parity instrument)
 // ================================================================================================
 #define F_TF 64
@@ -259,7 +396,21 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmDev p, int n_ftiles) {
 }
 
 template <int EPI>
-static int launch(const GemmDev& d, int dtype, hipStream_t s) {
+static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
+  if (dtype == TTV_BF16 && d.K == 256) {
+    const int fo = (EPI == EPI_GEGLU) ? 32 : 64;
+    const int n_panels = ttv_cdiv(d.N, fo), n_tiles = ttv_cdiv(d.M, K256_TT);
+    const int total = n_panels * n_tiles;
+    const int grid = total < 512 ? total : 512;   // 2 co-resident blocks per CU
+    if (prenorm) hipLaunchKernelGGL((k_gemm_k256<EPI, true>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
+    else hipLaunchKernelGGL((k_gemm_k256<EPI, false>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
+    TTV_CHECK_LAUNCH("gemm_k256");
+    return TTV_OK;
+  }
+  if (prenorm) {
+    ttv_set_error("gemm: folded pre-norm needs the bf16 K=256 kernel");
+    return TTV_ERR_UNSUPPORTED;
+  }
   if (dtype == TTV_BF16) {
     const int ft = (EPI == EPI_GEGLU) ? 64 : TF;
     const int nf = ttv_cdiv(d.N, ft), nt = ttv_cdiv(d.M, TT);
@@ -287,20 +438,22 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.M = a.M; d.N = a.N; d.K = a.K; d.alpha = a.alpha;
   d.w_rows = (epi == EPI_GEGLU) ? 2 * a.N : a.N;
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end;
+  d.eps = a.eps;
+  const bool pn = a.prenorm != 0;
   const int kc = epi == EPI_STORE ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : epi == EPI_GEGLU ? TTV_KC_GEMM_GEGLU : TTV_KC_GEMM_RESID;
   TtvProfScope prof(kc, s);
   switch (epi) {
-    case EPI_STORE: return launch<EPI_STORE>(d, a.dtype, s);
+    case EPI_STORE: return launch<EPI_STORE>(d, a.dtype, pn, s);
     case EPI_QKV_ROPE:
       TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 64 == 0 && a.rope_k_begin % 64 == 0 && a.rope_k_end % 64 == 0, "gemm: rotary ranges must be head (64) aligned");
-      return launch<EPI_QKV_ROPE>(d, a.dtype, s);
-    case EPI_GEGLU: return launch<EPI_GEGLU>(d, a.dtype, s);
+      return launch<EPI_QKV_ROPE>(d, a.dtype, pn, s);
+    case EPI_GEGLU: return launch<EPI_GEGLU>(d, a.dtype, pn, s);
     case EPI_RESID_T:
       TTV_CHECK_ARG(a.resid && a.ldr % 4 == 0, "gemm: residual missing");
-      return launch<EPI_RESID_T>(d, a.dtype, s);
+      return launch<EPI_RESID_T>(d, a.dtype, pn, s);
     case EPI_RESID_F32:
       TTV_CHECK_ARG(a.resid && a.ldr % 4 == 0, "gemm: residual missing");
-      return launch<EPI_RESID_F32>(d, a.dtype, s);
+      return launch<EPI_RESID_F32>(d, a.dtype, pn, s);
   }
   ttv_set_error("gemm: unknown epilogue");
   return TTV_ERR_INVALID;

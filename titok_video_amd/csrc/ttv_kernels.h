@@ -46,6 +46,8 @@ struct GemmArgs {
   const float* rope_cs;            // [M,64]
   int rope_q_end, rope_k_begin, rope_k_end;  // column ranges [0,q_end) and [k_begin,k_end) get rotary
   int dtype;
+  int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
+  float eps;
 };
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 

@@ -132,6 +132,17 @@ class _WeightPack:
             keep.append(t)
             return t.data_ptr()
 
+        fold = dtype == torch.bfloat16 and tower.width == 256
+
+        def folded(w, g):
+            """w * gain[None, :] in fp32, then the compute dtype: lets the K=256 GEMM kernel absorb the pre-norm."""
+            if not fold:
+                return None
+            t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
+            t = t.to(dtype).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
         perm = tower._patch_perm().to(device)
         if tower.kind == _lib.TTV_ENCODER:
             w_in = tower.proj_in.weight.detach().to(device)[:, perm]
@@ -149,7 +160,8 @@ class _WeightPack:
                 pre_ln=gain(a.pre_ln.weight), to_qkv=lin(a.to_qkv.weight), out_proj=lin(a.out_proj.weight),
                 ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
-                ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None)
+                ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
+                to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight), w12_pn=folded(f.w12.weight, f.norm.weight))
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
