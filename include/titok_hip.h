@@ -88,6 +88,12 @@ int ttv_linear_geglu(const void* x, int ldx, const void* w, int ldw, void* y, in
 int ttv_linear_residual(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha, void* y,
                         int ldy, int y_f32, int M, int N, int K, int dtype, void* stream);
 
+/* The whole KEEL step of one sub-layer (transformer.py:141-142 / 144-145) in one kernel:
+ * y = RMSNorm(alpha*resid + x@w^T) * gain, stored in dtype (y may alias resid).  Returns TTV_ERR_UNSUPPORTED unless a
+ * full-row kernel exists for the shape (bf16, N == K == 256); callers then use ttv_linear_residual + ttv_rmsnorm. */
+int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha,
+                             const float* gain, float eps, void* y, int ldy, int M, int N, int K, int dtype, void* stream);
+
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
  * Non-causal, block-diagonal over cu_seqlens (device int32 [n_seq+1]), GQA, softmax scale head_dim^-0.5.
@@ -198,6 +204,8 @@ int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int c
 /* Start recording launches of `kernel_class` (up to max_records; events are created here, outside any launch path).
  * This is the only process-global state in the library and it is off by default. */
 int ttv_prof_begin(int kernel_class, int max_records);
+/* Diagnostics for kernel ablation timing (never set in product use): bit0 = GEMM epilogues skip their stores. */
+int ttv_debug_set(int flags);
 /* Synchronise the recorded events, return their summed duration (ms) and count, and release them. */
 int ttv_prof_end(double* total_ms, int* count);
 

@@ -213,6 +213,24 @@ def test_linear_residual(dt, f32out):
         assert_close(rd.float(), r.double() + x.double() @ w.double().T, dt)
 
 
+@pytest.mark.parametrize("M", [1, 63, 64, 200, 4097])
+def test_linear_residual_norm_fused(M):
+    """KEEL step in one kernel (bf16, N = K = 256): y = RMSNorm(alpha*resid + x@w^T)*gain, in place on resid."""
+    N = K = 256
+    x, w, g = _lin_inputs(M, N, K, "bf16", 17 + M)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    gain = 1 + 0.1 * torch.randn(N, generator=g)
+    xd, wd, rd, gd = x.to(DEV), w.to(DEV), r.to(DEV), gain.to(DEV)
+    _lib.check(L().ttv_linear_residual_norm(xd.data_ptr(), K, wd.data_ptr(), K, rd.data_ptr(), N, 8.0, gd.data_ptr(), 1e-5,
+                                            rd.data_ptr(), N, M, N, K, _lib.TTV_BF16, S()), "resid_norm")
+    y = 8.0 * r.double() + x.double() @ w.double().T
+    ref = y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-5) * gain.double()
+    assert_close(rd.float(), ref, "bf16")
+    rc = L().ttv_linear_residual_norm(xd.data_ptr(), K, wd.data_ptr(), K, rd.data_ptr(), N, 8.0, gd.data_ptr(), 1e-5,
+                                      rd.data_ptr(), N, M, N, K, _lib.TTV_F32, S())
+    assert rc == 3      # TTV_ERR_UNSUPPORTED: callers fall back to linear_residual + rmsnorm
+
+
 # ---------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("case", [([(4, 16, 16)], [1]), ([(8, 32, 48), (4, 8, 24), (16, 64, 64)], [5, 3, 128]),

@@ -66,6 +66,8 @@ SYMBOLS = {
     "ttv_linear_geglu": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_linear_residual": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, vp]),
+    "ttv_linear_residual_norm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, f32, vp, f32, vp, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, vp]),
     "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                    C.c_int, C.c_int, vp]),
@@ -77,6 +79,7 @@ SYMBOLS = {
     "ttv_decoder_forward": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(Batch), vp, C.POINTER(vp),
                                       vp, i64, vp]),
     "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
+    "ttv_debug_set": (C.c_int, [C.c_int]),
     "ttv_prof_begin": (C.c_int, [C.c_int, C.c_int]),
     "ttv_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -18,6 +18,7 @@ void ttv_set_error(const char* fmt, ...) {
 
 // ---- measurement hook ----
 int g_ttv_prof_class = 0;
+int g_ttv_debug = 0;
 static hipEvent_t* g_prof_start = nullptr;
 static hipEvent_t* g_prof_stop = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
@@ -101,6 +102,11 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     if (i == 0) {
       o.alpha = 1.f; o.y = ws.x; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
+    } else if (ttvk_gemm_supports_resid_norm(dt, dm, dm)) {
+      // x <- RMSNorm(alpha*x + ao@Wo^T) * gain in one kernel; in place on x is safe: a token row is read (as residual)
+      // and written by the same wave only
+      o.alpha = d->alpha; o.y = ws.x; o.ldy = dm; o.norm_gain = lw.attn_post_ln; o.eps = d->eps;
+      TTV_TRY(ttvk_gemm(EPI_RESID_NORM, o, s));
     } else {
       o.alpha = d->alpha; o.y = ws.y32; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
@@ -191,6 +197,19 @@ int ttv_linear_residual(const void* x, int ldx, const void* w, int ldw, const vo
   return ttvk_gemm(y_f32 ? EPI_RESID_F32 : EPI_RESID_T, a, (hipStream_t)stream);
 }
 
+int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha,
+                             const float* gain, float eps, void* y, int ldy, int M, int N, int K, int dtype, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (x && w && y && resid && gain), "linear_residual_norm: null buffer");
+  GemmArgs a = {};
+  a.dtype = dtype; a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy;
+  a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.norm_gain = gain; a.eps = eps;
+  if (!ttvk_gemm_supports_resid_norm(dtype, N, K)) {
+    ttv_set_error("linear_residual_norm: only bf16 with N == K == 256 has a fused kernel");
+    return TTV_ERR_UNSUPPORTED;
+  }
+  return ttvk_gemm(EPI_RESID_NORM, a, (hipStream_t)stream);
+}
+
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream) {
   TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention: null buffer");
@@ -275,6 +294,11 @@ int ttv_decoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
     const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
     TTV_TRY(ttvk_patch_copy(true, clips_out + c0, b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.pa, pd, dt, b->max_patches_per_clip, s));
   }
+  return TTV_OK;
+}
+
+int ttv_debug_set(int flags) {
+  g_ttv_debug = flags;
   return TTV_OK;
 }
 

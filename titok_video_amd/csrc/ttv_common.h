@@ -77,6 +77,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- optional HIP-event bracketing of one kernel class (ttv_prof_begin / ttv_prof_end) ----------------
 extern int g_ttv_prof_class;
+extern int g_ttv_debug;
 struct TtvProfScope {
   int slot;
   hipStream_t s;

@@ -1,15 +1,25 @@
 // Linear layers of the TiTok-Video towers (proj_in/out, to_qkv, out_proj, w12, w3) as y = x @ w^T.
 //
 // Orientation: the MFMA "row" (A) operand is the WEIGHT tile (output features), the "column" (B) operand the
-// TOKEN tile, i.e. the kernel computes y^T = w @ x^T.  With mfma_f32_16x16x32_bf16's C layout
+// TOKEN tile, i.e. the kernels compute y^T = w @ x^T.  With mfma_f32_16x16x32_bf16's C layout
 // (col = lane&15, row = 4*(lane>>4)+reg) a lane then owns 4 CONSECUTIVE output features of one token, so
-// rotary pairs, GEGLU's (x, gate) pair, bias and the residual are lane-local and the store is one 8-byte vector.
-// Both operands are K-contiguous in memory ([N,K] weights, [M,K] activations), which is what MFMA wants.
+// rotary pairs, GEGLU's (x, gate) pair, bias and the residual are lane-local.  Both operands are K-contiguous in
+// memory ([N,K] weights, [M,K] activations), which is what MFMA wants.
 //
-// bf16 path : 128 features x 128 tokens x 64 K per step, 4 waves (2x2), each 64x64 = 4x4 MFMA tiles,
-//             register-staged double-buffered LDS, XOR-swizzled 16-byte chunks (conflict-free ds_read_b128),
-//             XCD-aware tile order (feature tile fastest so the token tile is re-read from the same L2).
-// fp32 path : parity instrument only (the reference never runs fp32 on GPU): 64x64x16 tiles, VALU FMAs.
+// Epilogue (epilogue_tile): all side loads of a wave's tile (rotary table / residual / bias) are issued first,
+// then the math, then the stores - no per-element branch, so nothing serialises on a memory round trip.  bf16 rows
+// are written as 16-byte vectors: lanes kq and kq^1 (lane ^ 16) swap one 4-feature group so that each holds 8
+// consecutive features (64 contiguous bytes per token per store instruction).
+//
+// Kernels
+//   k_gemm_k256 : K == 256 (every to_qkv / w12 / out_proj / decoder proj_out of a width-256 tower).  These GEMMs
+//                 are HBM-bound (192 FLOP/B at N=768), so the structure minimises traffic and exposed latency:
+//                 a wave keeps its 32 tokens x K in registers (loaded once per 128-token tile), 64-row weight
+//                 panels stream through double-buffered LDS, blocks are persistent over contiguous
+//                 (token tile, panel) items, and the preceding RMSNorm is folded in (PRENORM).
+//   k_gemm_bf16 : general K: 128 features x 128 tokens x 64 K tiles, 4 waves (2x2), register-staged double-buffered
+//                 LDS, XOR-swizzled 16-byte chunks (conflict-free ds_read_b128), XCD-aware tile order.
+//   k_gemm_f32  : parity instrument only (the reference never runs fp32 on GPU): 64x64x16 tiles, VALU FMAs.
 #include "ttv_common.h"
 #include "ttv_kernels.h"
 
@@ -22,52 +32,158 @@ struct GemmDev {
   float alpha;
   int rope_q_end, rope_k_begin, rope_k_end;
   float eps;  // RMSNorm eps for the folded pre-norm (k256 kernel)
+  int debug;  // diagnostics (ttv_debug_set): bit0 = skip epilogue stores
+  const float* norm_gain;
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-// Lane-local epilogue on 4 consecutive features [f0, f0+4) of token t.  acc2 is the gate half for EPI_GEGLU.
-template <int EPI, typename T>
-__device__ __forceinline__ void epilogue(const GemmDev& p, int t, int f0, f32x4 acc, f32x4 acc2) {
-  if (t >= p.M || f0 >= p.N) return;
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16 resolution) for the bf16 GEGLU epilogue:
+// one v_rcp, one v_exp and a degree-5 Horner chain instead of libm's branchy erff.
+__device__ __forceinline__ float gelu_erf_fast(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erf_abs = 1.0f - poly * e;
+  const float erf_v = v < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * v * (1.0f + erf_v);
+}
+
+__device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
+  bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  return __builtin_bit_cast(uint2, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-tile epilogue.  acc[i][j]: output m-tile i (features feat[i] .. feat[i]+3 for this lane), n-tile j (token tok[j]).
+// acc2 = gate half for EPI_GEGLU.  kq = lane >> 4.  T = storage type of x / y / resid.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename T, int NI, int NJ>
+__device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)[NJ], const int (&feat)[NI],
+                                              f32x4 (&acc)[NI][NJ], f32x4 (&acc2)[NI][NJ], int kq) {
+  if (p.debug & 1) {  // timing-only path: keep the values alive, store nothing
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][3]), "v"(acc2[i][j][1]));
+    return;
+  }
+  int tc[NJ], fc[NI];
+  bool tv[NJ], fv[NI];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { tv[j] = tok[j] < p.M; tc[j] = tv[j] ? tok[j] : p.M - 1; }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { fv[i] = feat[i] < p.N; fc[i] = fv[i] ? feat[i] : p.N - 4; }
+
   if (EPI == EPI_STORE) {
     if (p.bias) {
-      const f32x4 b = Vec4<T>::load((const T*)p.bias + f0);
-      acc += b;
+      f32x4 b[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) b[i] = Vec4<T>::load((const T*)p.bias + fc[i]);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] += b[i];
     }
     if (p.add_scalar) {
       const float sc = round_to<T>(p.add_scalar[0]);
-      if (p.bias) {  // Linear output is rounded to dtype before the scalar is added (blocks.py:97)
-        acc = (f32x4){round_to<T>(acc[0]), round_to<T>(acc[1]), round_to<T>(acc[2]), round_to<T>(acc[3])};
-      }
-      acc += sc;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (p.bias) {  // the Linear output is rounded to dtype before the scalar is added (blocks.py:97)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = round_to<T>(acc[i][j][e]);
+          }
+          acc[i][j] += sc;
+        }
     }
-    Vec4<T>::store((T*)p.y + (size_t)t * p.ldy + f0, acc);
   } else if (EPI == EPI_QKV_ROPE) {
-    const bool rot = (f0 < p.rope_q_end) || (f0 >= p.rope_k_begin && f0 < p.rope_k_end);
-    if (rot) {
-      const int j = (f0 & 63) >> 1;
-      const float* cs = p.rope_cs + (size_t)t * 64 + j;
-      const float c0 = cs[0], c1 = cs[1], s0 = cs[32], s1 = cs[33];
-      acc = (f32x4){acc[0] * c0 - acc[1] * s0, acc[0] * s0 + acc[1] * c0, acc[2] * c1 - acc[3] * s1, acc[2] * s1 + acc[3] * c1};
+    // the rotary column ranges are multiples of the block's feature tile (checked on the host): uniform per block
+    const int f_first = __builtin_amdgcn_readfirstlane(feat[0]);
+    if (f_first < p.rope_q_end || (f_first >= p.rope_k_begin && f_first < p.rope_k_end)) {
+      float2 c[NI][NJ], s[NI][NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float* cs = p.rope_cs + (size_t)tc[j] * 64 + ((fc[i] & 63) >> 1);
+          c[i][j] = *reinterpret_cast<const float2*>(cs);
+          s[i][j] = *reinterpret_cast<const float2*>(cs + 32);
+        }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const f32x4 a = acc[i][j];
+          acc[i][j] = (f32x4){a[0] * c[i][j].x - a[1] * s[i][j].x, a[0] * s[i][j].x + a[1] * c[i][j].x,
+                              a[2] * c[i][j].y - a[3] * s[i][j].y, a[2] * s[i][j].y + a[3] * c[i][j].y};
+        }
     }
-    Vec4<T>::store((T*)p.y + (size_t)t * p.ldy + f0, acc);
   } else if (EPI == EPI_GEGLU) {
-    f32x4 o = {gelu_erf(acc2[0]) * acc[0], gelu_erf(acc2[1]) * acc[1], gelu_erf(acc2[2]) * acc[2], gelu_erf(acc2[3]) * acc[3]};
-    Vec4<T>::store((T*)p.y + (size_t)t * p.ldy + f0, o);
-  } else if (EPI == EPI_RESID_T) {
-    const f32x4 r = Vec4<T>::load((const T*)p.resid + (size_t)t * p.ldr + f0);
-    acc += p.alpha * r;
-    Vec4<T>::store((T*)p.y + (size_t)t * p.ldy + f0, acc);
-  } else {  // EPI_RESID_F32
-    const f32x4 r = Vec4<T>::load((const T*)p.resid + (size_t)t * p.ldr + f0);
-    acc += p.alpha * r;
-    *reinterpret_cast<f32x4*>((float*)p.y + (size_t)t * p.ldy + f0) = acc;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gl = sizeof(T) == 2 ? gelu_erf_fast(acc2[i][j][e]) : gelu_erf(acc2[i][j][e]);
+          acc[i][j][e] = gl * acc[i][j][e];
+        }
+  } else {  // EPI_RESID_T / EPI_RESID_F32
+    f32x4 r[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) r[i][j] = Vec4<T>::load((const T*)p.resid + (size_t)tc[j] * p.ldr + fc[i]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] += p.alpha * r[i][j];
+  }
+
+  // ---- stores ----
+  if (EPI == EPI_RESID_F32) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (tv[j] && fv[i]) *reinterpret_cast<f32x4*>((float*)p.y + (size_t)tok[j] * p.ldy + feat[i]) = acc[i][j];
+  } else if (sizeof(T) == 2 && (NI % 2 == 0)) {
+    // lanes kq / kq^1 exchange one 4-feature group: even kq keeps m-tile i0 (8 consecutive features from feat[i0]),
+    // odd kq keeps m-tile i1 (8 consecutive features from feat[i1]-4)
+    const bool odd = kq & 1;
+#pragma unroll
+    for (int ip = 0; ip < NI / 2; ++ip) {
+      const int i0 = 2 * ip, i1 = 2 * ip + 1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint2 p0 = pack_bf16x4(acc[i0][j]), p1 = pack_bf16x4(acc[i1][j]);
+        const uint2 send = odd ? p0 : p1;
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 16, 64);
+        recv.y = __shfl_xor(send.y, 16, 64);
+        const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        const int start = odd ? feat[i1] - 4 : feat[i0];
+        if (tv[j] && start + 8 <= p.N) *reinterpret_cast<uint4*>((T*)p.y + (size_t)tok[j] * p.ldy + start) = out;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (tv[j] && fv[i]) Vec4<T>::store((T*)p.y + (size_t)tok[j] * p.ldy + feat[i], acc[i][j]);
   }
 }
 
 // ================================================================================================
-// bf16 MFMA kernel
+// bf16 MFMA kernel, general K
 // ================================================================================================
 #define TF 128
 #define TT 128
@@ -94,7 +210,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
   const bf16_t* X = (const bf16_t*)p.x;
 
   // per-thread staging: 4 chunks (16 B) of each operand per k-tile; chunk = tid + 256*i -> row = chunk>>3, kc = chunk&7
-  // (row advances by 32 per i, kc is the same for all i)
   const int srow = tid >> 3, skc = tid & 7;
   const bf16_t* wp0; const bf16_t* wp1; const bf16_t* wp2; const bf16_t* wp3;
   const bf16_t* xp0; const bf16_t* xp1; const bf16_t* xp2; const bf16_t* xp3;
@@ -114,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     wp0 = wrow(srow); wp1 = wrow(srow + 32); wp2 = wrow(srow + 64); wp3 = wrow(srow + 96);
     xp0 = xrow(srow); xp1 = xrow(srow + 32); xp2 = xrow(srow + 64); xp3 = xrow(srow + 96);
   }
-  // swizzled LDS slot of (row, kc): row*8 + (kc ^ ((row>>1)&7)); rows srow+32*i share (row>>1)&7 up to +16*i
+  // swizzled LDS slot of (row, kc): row*8 + (kc ^ ((row>>1)&7))
   const int li0 = srow * 8 + (skc ^ ((srow >> 1) & 7));
   const int li1 = (srow + 32) * 8 + (skc ^ (((srow + 32) >> 1) & 7));
   const int li2 = (srow + 64) * 8 + (skc ^ (((srow + 64) >> 1) & 7));
@@ -146,7 +261,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     lds[buf][1][li0] = sx0; lds[buf][1][li1] = sx1; lds[buf][1][li2] = sx2; lds[buf][1][li3] = sx3; \
   } while (0)
 
-  // fragment rows: A (weights) rows of this wave's 4 m-tiles, B (tokens) rows of its 4 n-tiles
   const int l15 = lane & 15, kq = lane >> 4;
   const int nk = (p.K + BK - 1) / BK;
   GLOAD(0);
@@ -177,34 +291,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
 #undef GLOAD
 #undef LSTORE
 
-  // epilogue: lane owns features f0..f0+3 (4*(lane>>4)+reg) of token (lane&15) in every 16x16 tile
+  int tok[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t = tbase + wt * 64 + j * 16 + (lane & 15);
-    if (DUAL) {
+  for (int j = 0; j < 4; ++j) tok[j] = tbase + wt * 64 + j * 16 + l15;
+  if (DUAL) {
+    int feat[2];
+    f32x4 ax[2][4], ag[2][4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f0 = fbase + wf * 32 + i * 16 + (lane >> 4) * 4;
-        epilogue<EPI, bf16_t>(p, t, f0, acc[i][j], acc[i + 2][j]);
-      }
-    } else {
+    for (int i = 0; i < 2; ++i) {
+      feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int f0 = fbase + wf * 64 + i * 16 + (lane >> 4) * 4;
-        epilogue<EPI, bf16_t>(p, t, f0, acc[i][j], acc[i][j]);
-      }
+      for (int j = 0; j < 4; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
     }
+    epilogue_tile<EPI, bf16_t, 2, 4>(p, tok, feat, ax, ag, kq);
+  } else {
+    int feat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
+    epilogue_tile<EPI, bf16_t, 4, 4>(p, tok, feat, acc, acc, kq);
   }
 }
 
 // ================================================================================================
-// bf16 MFMA kernel for K == 256 (every to_qkv / w12 / out_proj / decoder proj_out of a width-256 tower)
+// bf16 MFMA kernel for K == 256
 //
-// With K this short a classic tiled GEMM spends its time in per-tile load latency, so this kernel keeps the TOKEN
-// operand in registers for the whole K (a wave owns 64 tokens: 4 n-tiles x 8 k-steps x 16 B = 128 VGPRs) and streams
-// 64-row WEIGHT panels (32 KiB) through double-buffered LDS.  Blocks are persistent over a contiguous range of
-// (token tile, panel) items, so the token registers are loaded once per 128-token tile and the steady state is
-// {prefetch next panel -> 64 MFMA per wave from LDS -> epilogue -> stage -> one barrier}.
+// 4 waves, each owning 32 tokens of a 128-token tile with the whole K in registers (2 n-tiles x 8 k-steps x 16 B =
+// 64 VGPRs) and computing them against ALL 64 rows of the current weight panel (4 m-tiles): per item 64 MFMAs per
+// wave, A fragments re-read from the shared LDS panel, B fragments never re-read.  A wave therefore writes
+// 64 (32 for GEGLU) consecutive output features per token.  Item order per block: contiguous (tile, panel) range.
+// Loop body: prefetch next panel (global->regs) | 64 MFMA | stage next panel to LDS | epilogue | barrier - the
+// panel's vmcnt wait sits BEFORE the epilogue's stores so it never drains them (vmcnt retires in issue order).
 //
 // PRENORM: the preceding RMSNorm (transformer.py:86 / :48) is folded in: its gain is pre-multiplied into the weight
 // columns on the host (w' = w * gain), and rstd = rsqrt(mean(x^2)+eps) is computed here from the register-resident
@@ -220,7 +336,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   __shared__ uint4 wl[2][K256_ROWS * 32];  // [buffer][row*32 + swizzled 16-byte chunk], 2 x 32 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wf = wave & 1, wt = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
   const int it0 = (int)((long)total_items * blockIdx.x / gridDim.x);
   const int it1 = (int)((long)total_items * (blockIdx.x + 1) / gridDim.x);
@@ -251,13 +366,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
     wl[buf_][LIDX(4)] = st4; wl[buf_][LIDX(5)] = st5; wl[buf_][LIDX(6)] = st6; wl[buf_][LIDX(7)] = st7;      \
   } while (0)
 
-  // A-fragment rows of this wave inside a panel
-  const int arow0 = (DUAL ? wf * 16 : wf * 32) + l15;
-  const int arow1 = (DUAL ? 32 + wf * 16 : wf * 32 + 16) + l15;
-
-  bf16x8 bfr[4][8];
-  float rstd[4] = {1.f, 1.f, 1.f, 1.f};
+  bf16x8 bfr[2][8];
+  float rstd[2] = {1.f, 1.f};
   int cur_tile = -1;
+  // EPI_QKV_ROPE: every rotary panel is one 64-wide head, so the (cos, sin) pairs this lane needs depend only on the
+  // token: feature i*16 + kq*4 + {0..3} -> complex pairs i*8 + kq*2 + {0,1}.  Kept in registers per token tile.
+  float2 rc[4][2], rs[4][2];
 
   GLOADP(it0 % n_panels);
   LSTOREP(0);
@@ -265,19 +379,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
     const int tile = it / n_panels, panel = it - tile * n_panels;
-    if (tile != cur_tile) {
+    if (tile != cur_tile && !((p.debug & 4) && cur_tile >= 0)) {
       cur_tile = tile;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int t = tile * K256_TT + wt * 64 + j * 16 + l15;
+      for (int j = 0; j < 2; ++j) {
+        int t = tile * K256_TT + wave * 32 + j * 16 + l15;
         t = t < p.M ? t : p.M - 1;
         const bf16_t* xr = X + (size_t)t * p.ldx + kq * 8;
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
       }
+      if (EPI == EPI_QKV_ROPE) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int t = tile * K256_TT + wave * 32 + j * 16 + l15;
+          t = t < p.M ? t : p.M - 1;
+          const float* cs = p.rope_cs + (size_t)t * 64 + kq * 2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            rc[i][j] = *reinterpret_cast<const float2*>(cs + i * 8);
+            rs[i][j] = *reinterpret_cast<const float2*>(cs + 32 + i * 8);
+          }
+        }
+      }
       if (PRENORM) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
           float ss = 0.f;
 #pragma unroll
           for (int s8 = 0; s8 < 8; ++s8)
@@ -292,45 +419,181 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
         }
       }
     }
-    if (it + 1 < it1) GLOADP((it + 1) % n_panels);
+    if (it + 1 < it1 && !(p.debug & 2)) GLOADP((it + 1) % n_panels);
 
-    f32x4 acc[2][4];
+    f32x4 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
       const int ch = s8 * 4 + kq;
-      const bf16x8 a0 = __builtin_bit_cast(bf16x8, wl[buf][arow0 * 32 + ((ch & 16) | ((ch & 15) ^ (arow0 & 15)))]);
-      const bf16x8 a1 = __builtin_bit_cast(bf16x8, wl[buf][arow1 * 32 + ((ch & 16) | ((ch & 15) ^ (arow1 & 15)))]);
+      bf16x8 a[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[j][s8], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[j][s8], acc[1][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int arow = i * 16 + l15;
+        a[i] = __builtin_bit_cast(bf16x8, wl[buf][arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = tile * K256_TT + wt * 64 + j * 16 + l15;
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[j][s8], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < it1 && !(p.debug & 2)) LSTOREP(buf ^ 1);   // waits for the panel loads only: no younger memory op has been issued yet
+
+    int tok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      tok[j] = tile * K256_TT + wave * 32 + j * 16 + l15;
       if (PRENORM) {
-        acc[0][j] *= rstd[j];
-        acc[1][j] *= rstd[j];
-      }
-      if (DUAL) {
-        epilogue<EPI, bf16_t>(p, t, panel * FO + wf * 16 + kq * 4, acc[0][j], acc[1][j]);
-      } else {
-        epilogue<EPI, bf16_t>(p, t, panel * FO + wf * 32 + kq * 4, acc[0][j], acc[0][j]);
-        epilogue<EPI, bf16_t>(p, t, panel * FO + wf * 32 + 16 + kq * 4, acc[1][j], acc[1][j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] *= rstd[j];
       }
     }
-    if (it + 1 < it1) LSTOREP(buf ^ 1);
+    if (DUAL) {  // panel rows 0..31 = x features, 32..63 = their gate rows
+      int feat[2] = {panel * FO + kq * 4, panel * FO + 16 + kq * 4};
+      f32x4 ax[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+      f32x4 ag[2][2] = {{acc[2][0], acc[2][1]}, {acc[3][0], acc[3][1]}};
+      epilogue_tile<EPI, bf16_t, 2, 2>(p, tok, feat, ax, ag, kq);
+    } else if (EPI == EPI_QKV_ROPE) {
+      int feat[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) feat[i] = panel * FO + i * 16 + kq * 4;
+      const int f_first = panel * FO;
+      if (f_first < p.rope_q_end || (f_first >= p.rope_k_begin && f_first < p.rope_k_end)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const f32x4 a = acc[i][j];
+            acc[i][j] = (f32x4){a[0] * rc[i][j].x - a[1] * rs[i][j].x, a[0] * rs[i][j].x + a[1] * rc[i][j].x,
+                                a[2] * rc[i][j].y - a[3] * rs[i][j].y, a[2] * rs[i][j].y + a[3] * rc[i][j].y};
+          }
+      }
+      epilogue_tile<EPI_STORE, bf16_t, 4, 2>(p, tok, feat, acc, acc, kq);   // bias / add_scalar are null for to_qkv
+    } else {
+      int feat[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) feat[i] = panel * FO + i * 16 + kq * 4;
+      epilogue_tile<EPI, bf16_t, 4, 2>(p, tok, feat, acc, acc, kq);
+    }
     __syncthreads();
   }
 #undef WROW
 #undef GLOADP
 #undef LIDX
 #undef LSTOREP
+}
+
+// ================================================================================================
+// out_proj of a width-256 tower fused with the whole KEEL step (transformer.py:141-142):
+//     x_new = RMSNorm(alpha * x + ao @ Wo^T) * gain          (K == 256, N == 256, bf16)
+// Same register-resident-token structure as k_gemm_k256, but a wave keeps the accumulators of ALL 256 output features of
+// its 16 tokens (16 m-tiles), so the row statistics are wave-local: in-lane sum of 64 squares + two xor shuffles.
+// Nothing is written in fp32 and no separate norm pass exists.  The 4 weight panels cycle 0,1,2,3,0,1,... across tiles,
+// so the LDS double-buffer prefetch never drains at a tile boundary.
+// ================================================================================================
+#define ROW_TT 64
+
+__global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_tiles) {
+  __shared__ uint4 wl[2][K256_ROWS * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  if ((int)blockIdx.x >= n_tiles) return;
+  const bf16_t* W = (const bf16_t*)p.w;
+  const bf16_t* X = (const bf16_t*)p.x;
+  const int srow = tid >> 5, sch = tid & 31;
+  uint4 st0, st1, st2, st3, st4, st5, st6, st7;
+#define WROWN(panel_, i_) (*reinterpret_cast<const uint4*>(W + (size_t)((panel_) * 64 + srow + 8 * (i_)) * p.ldw + sch * 8))
+#define GLOADN(panel_)                                                                                       \
+  do {                                                                                                       \
+    st0 = WROWN(panel_, 0); st1 = WROWN(panel_, 1); st2 = WROWN(panel_, 2); st3 = WROWN(panel_, 3);          \
+    st4 = WROWN(panel_, 4); st5 = WROWN(panel_, 5); st6 = WROWN(panel_, 6); st7 = WROWN(panel_, 7);          \
+  } while (0)
+#define LIDXN(i_) ((srow + 8 * (i_)) * 32 + ((sch & 16) | ((sch & 15) ^ ((srow + 8 * (i_)) & 15))))
+#define LSTOREN(buf_)                                                                                        \
+  do {                                                                                                       \
+    wl[buf_][LIDXN(0)] = st0; wl[buf_][LIDXN(1)] = st1; wl[buf_][LIDXN(2)] = st2; wl[buf_][LIDXN(3)] = st3;  \
+    wl[buf_][LIDXN(4)] = st4; wl[buf_][LIDXN(5)] = st5; wl[buf_][LIDXN(6)] = st6; wl[buf_][LIDXN(7)] = st7;  \
+  } while (0)
+
+  GLOADN(0);
+  LSTOREN(0);
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const bool last_tile = tile + (int)gridDim.x >= n_tiles;
+    int t = tile * ROW_TT + wave * 16 + l15;
+    const bool tvalid = t < p.M;
+    t = tvalid ? t : p.M - 1;
+    bf16x8 bfr[8];
+    {
+      const bf16_t* xr = X + (size_t)t * p.ldx + kq * 8;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) bfr[s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int panel = 0; panel < 4; ++panel) {
+      const int buf = panel & 1;   // 4 panels per tile: the buffer parity is the same for every tile
+      const bool more = !(last_tile && panel == 3);
+      if (more) GLOADN((panel + 1) & 3);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const int ch = s8 * 4 + kq;
+        bf16x8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int arow = i * 16 + l15;
+          a[i] = __builtin_bit_cast(bf16x8, wl[buf][arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[panel * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[s8], acc[panel * 4 + i], 0, 0, 0);
+      }
+      if (more) LSTOREN(buf ^ 1);
+      __syncthreads();
+    }
+    // ---- y = alpha*resid + acc ; x_new = y * rsqrt(mean(y^2)+eps) * gain ----
+    const bf16_t* rrow = (const bf16_t*)p.resid + (size_t)t * p.ldr + kq * 4;
+    f32x4 r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = Vec4<bf16_t>::load(rrow + i * 16);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i] += p.alpha * r[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss = fmaf(acc[i][e], acc[i][e], ss);
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+    const bool odd = kq & 1;
+    bf16_t* yrow = (bf16_t*)p.y + (size_t)t * p.ldy;
+#pragma unroll
+    for (int ip = 0; ip < 8; ++ip) {
+      const int i0 = 2 * ip, i1 = 2 * ip + 1;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.norm_gain + i0 * 16 + kq * 4);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.norm_gain + i1 * 16 + kq * 4);
+      f32x4 y0, y1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][e] * rstd * g0[e]; y1[e] = acc[i1][e] * rstd * g1[e]; }
+      const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
+      const uint2 send = odd ? p0 : p1;
+      uint2 recv;
+      recv.x = __shfl_xor(send.x, 16, 64);
+      recv.y = __shfl_xor(send.y, 16, 64);
+      const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+      const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
+      if (tvalid && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = out;
+    }
+  }
+#undef WROWN
+#undef GLOADN
+#undef LIDXN
+#undef LSTOREN
 }
 
 // ================================================================================================
@@ -386,18 +649,21 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmDev p, int n_ftiles) {
         }
     }
   }
+  // one "m-tile" of 4 consecutive features, 4 "n-tiles" of one token each
+  int tok[4], feat[1] = {fbase + tf * 4};
+  f32x4 v[1][4], v2[1][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int t = tbase + tt * 4 + j;
-    const f32x4 v = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-    const f32x4 v2 = {acc2[0][j], acc2[1][j], acc2[2][j], acc2[3][j]};
-    epilogue<EPI, float>(p, t, fbase + tf * 4, v, v2);
+    tok[j] = tbase + tt * 4 + j;
+    v[0][j] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+    v2[0][j] = (f32x4){acc2[0][j], acc2[1][j], acc2[2][j], acc2[3][j]};
   }
+  epilogue_tile<EPI, float, 1, 4>(p, tok, feat, v, v2, 0);
 }
 
 template <int EPI>
 static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
-  if (dtype == TTV_BF16 && d.K == 256) {
+  if (dtype == TTV_BF16 && d.K == 256 && d.N % 8 == 0) {
     const int fo = (EPI == EPI_GEGLU) ? 32 : 64;
     const int n_panels = ttv_cdiv(d.N, fo), n_tiles = ttv_cdiv(d.M, K256_TT);
     const int total = n_panels * n_tiles;
@@ -423,6 +689,8 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
   return TTV_OK;
 }
 
+bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K) { return dtype == TTV_BF16 && N == 256 && K == 256; }
+
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   if (a.M == 0 || a.N == 0) return TTV_OK;
   const int esz = a.dtype == TTV_BF16 ? 2 : 4;
@@ -430,8 +698,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   TTV_CHECK_ARG(a.dtype == TTV_BF16 || a.dtype == TTV_F32, "gemm: bad dtype %d", a.dtype);
   TTV_CHECK_ARG(a.K > 0 && a.K % vec == 0, "gemm: K=%d must be a multiple of %d", a.K, vec);
   TTV_CHECK_ARG(a.N % 4 == 0, "gemm: N=%d must be a multiple of 4", a.N);
-  TTV_CHECK_ARG(a.ldx % vec == 0 && a.ldw % vec == 0 && a.ldy % 4 == 0, "gemm: leading dims must keep 16-byte row alignment");
-  TTV_CHECK_ARG(((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 8 == 0), "gemm: pointers must be 16-byte aligned");
+  TTV_CHECK_ARG(a.ldx % vec == 0 && a.ldw % vec == 0 && a.ldy % vec == 0, "gemm: leading dims must keep 16-byte row alignment");
+  TTV_CHECK_ARG(((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0), "gemm: pointers must be 16-byte aligned");
   GemmDev d;
   d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs;
   d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = a.ldy; d.ldr = a.ldr;
@@ -439,13 +707,16 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.w_rows = (epi == EPI_GEGLU) ? 2 * a.N : a.N;
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end;
   d.eps = a.eps;
+  d.debug = g_ttv_debug;
+  d.norm_gain = a.norm_gain;
   const bool pn = a.prenorm != 0;
   const int kc = epi == EPI_STORE ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : epi == EPI_GEGLU ? TTV_KC_GEMM_GEGLU : TTV_KC_GEMM_RESID;
   TtvProfScope prof(kc, s);
   switch (epi) {
     case EPI_STORE: return launch<EPI_STORE>(d, a.dtype, pn, s);
     case EPI_QKV_ROPE:
-      TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 64 == 0 && a.rope_k_begin % 64 == 0 && a.rope_k_end % 64 == 0, "gemm: rotary ranges must be head (64) aligned");
+      // rotary ranges must be multiples of the largest feature tile (128) so that "rotate or not" is uniform per block
+      TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 128 == 0 && a.rope_k_begin % 128 == 0 && a.rope_k_end % 128 == 0, "gemm: rotary ranges must be multiples of 128 columns");
       return launch<EPI_QKV_ROPE>(d, a.dtype, pn, s);
     case EPI_GEGLU: return launch<EPI_GEGLU>(d, a.dtype, pn, s);
     case EPI_RESID_T:
@@ -454,6 +725,15 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     case EPI_RESID_F32:
       TTV_CHECK_ARG(a.resid && a.ldr % 4 == 0, "gemm: residual missing");
       return launch<EPI_RESID_F32>(d, a.dtype, pn, s);
+    case EPI_RESID_NORM: {
+      TTV_CHECK_ARG(ttvk_gemm_supports_resid_norm(a.dtype, a.N, a.K), "gemm: fused residual+norm needs bf16, N == K == 256");
+      TTV_CHECK_ARG(a.resid && a.norm_gain && a.ldr % 4 == 0 && a.ldw >= 256, "gemm: residual / gain missing");
+      TTV_CHECK_ARG(a.y != a.x, "gemm: fused residual+norm output must not alias the GEMM input");
+      const int n_tiles = ttv_cdiv(a.M, ROW_TT);
+      hipLaunchKernelGGL(k_gemm_k256_rownorm, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), 0, s, d, n_tiles);
+      TTV_CHECK_LAUNCH("gemm_k256_rownorm");
+      return TTV_OK;
+    }
   }
   ttv_set_error("gemm: unknown epilogue");
   return TTV_ERR_INVALID;

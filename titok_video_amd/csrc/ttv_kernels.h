@@ -32,6 +32,8 @@ enum GemmEpilogue {
   EPI_GEGLU,       // y[:, f] = gelu(acc[:, I+f]) * acc[:, f]           (transformer.py:51-52)
   EPI_RESID_T,     // y = alpha*resid + acc, stored in dtype            (layer 0 residual, transformer.py:129-130)
   EPI_RESID_F32,   // y = alpha*resid + acc, stored fp32                (KEEL pre-post-norm sum, transformer.py:141,144)
+  EPI_RESID_NORM,  // y = RMSNorm(alpha*resid + acc) * norm_gain, stored in dtype (whole KEEL step, transformer.py:141-145);
+                   // needs a kernel whose waves own full rows: bf16, K == 256, N == 256 (ttvk_gemm_supports_resid_norm)
 };
 
 struct GemmArgs {
@@ -46,10 +48,12 @@ struct GemmArgs {
   const float* rope_cs;            // [M,64]
   int rope_q_end, rope_k_begin, rope_k_end;  // column ranges [0,q_end) and [k_begin,k_end) get rotary
   int dtype;
+  const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
   float eps;
 };
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 
 // ---- ttv_attn.hip ----
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
