@@ -1,0 +1,2 @@
+"""Mirror of the reference's `model` package for the tokenizer path (titok, base.blocks, base.utils, quantizer.fsq)."""
+from . import base, quantizer  # noqa: F401

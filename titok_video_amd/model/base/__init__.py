@@ -1,0 +1,1 @@
+from . import blocks, utils  # noqa: F401

@@ -1,0 +1,1 @@
+from . import fsq  # noqa: F401
