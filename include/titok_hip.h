@@ -94,6 +94,13 @@ int ttv_linear_residual(const void* x, int ldx, const void* w, int ldw, const vo
 int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha,
                              const float* gain, float eps, void* y, int ldy, int M, int N, int K, int dtype, void* stream);
 
+/* Whole GEGLU sub-layer (transformer.py:47-56) + residual/KEEL step (:130, :144-145) in one kernel, bf16, width 256:
+ * y = [RMSNorm](alpha*x + (gelu(xn@w12[I:]^T) * (xn@w12[:I]^T)) @ w3^T) [* post_gain], xn = RMSNorm(x)*norm_gain.
+ * w12_folded = w12 * norm_gain[None,:]; w3_perm as in ttv_layer_weights; post_gain NULL = plain residual (layer 0).
+ * y may alias x.  TTV_ERR_UNSUPPORTED for other dtypes/widths. */
+int ttv_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
+                  const float* post_gain, float alpha, float eps, int M, int width, int dtype, void* stream);
+
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
  * Non-causal, block-diagonal over cu_seqlens (device int32 [n_seq+1]), GQA, softmax scale head_dim^-0.5.
@@ -140,6 +147,9 @@ typedef struct ttv_layer_weights {
    * (w * gain[None,:]); when non-NULL the pre-norm runs inside the GEMM (rstd from the register-resident row) */
   const void* to_qkv_pn;
   const void* w12_pn;
+  /* optional (bf16, width 256): w3 with its columns permuted inside every 32-column panel to the k order of the fused
+   * feed-forward kernel: w3_perm[:, 32p + 8q + j] = w3[:, 32p + (j<4 ? 4q+j : 16+4q+(j-4))] */
+  const void* w3_perm;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {

@@ -2,6 +2,7 @@
 // sequences of the encoder / decoder towers.  Everything here only enqueues on the caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ttv_common.h"
@@ -113,6 +114,15 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
+    // Opt-in (TTV_FUSED_MLP=1): correct and parity-tested, but at one wave per SIMD it is not yet faster than the two
+    // GEMM kernels below; kept off the default path until the 8-wave version lands.
+    static const bool use_fused_mlp = getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '1';
+    if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.w12_pn && lw.w3_perm) {
+      // one kernel: pre-norm + w12 + GEGLU + w3 + residual/KEEL + post-norm, in place on x
+      TTV_TRY(ttvk_mlp_fused(ws.x, dm, lw.w12_pn, lw.w3_perm, d->inner, ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln,
+                             i == 0 ? 1.f : d->alpha, d->eps, L, s));
+      continue;
+    }
     const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
     if (!fold_ffd) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
@@ -208,6 +218,15 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
     return TTV_ERR_UNSUPPORTED;
   }
   return ttvk_gemm(EPI_RESID_NORM, a, (hipStream_t)stream);
+}
+
+int ttv_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
+                  const float* post_gain, float alpha, float eps, int M, int width, int dtype, void* stream) {
+  if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
+    ttv_set_error("mlp_fused: only bf16, width 256, inner %% 32 == 0");
+    return TTV_ERR_UNSUPPORTED;
+  }
+  return ttvk_mlp_fused(x, ldx, w12_folded, w3_perm, inner, y, ldy, post_gain, alpha, eps, M, (hipStream_t)stream);
 }
 
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,

@@ -80,8 +80,23 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
     for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // transposed-read lane geometry (16-lane groups): lane 4q+p of a group addresses row q, columns 4p..4p+3
+  // ---- lane-constant LDS byte offsets, hoisted out of the key loop (all per-tile variation is an immediate) ----
+  // K fragment (A operand of S^T): key row t*32 + r, 16-byte chunk (2ks + h) ^ ((row>>1)&7); (row>>1)&7 == (r>>1)&7
+  const int ksw = (r >> 1) & 7;
+  const int koff0 = r * 128 + (((0 * 2 + h) ^ ksw) << 4);
+  const int koff1 = r * 128 + (((1 * 2 + h) ^ ksw) << 4);
+  const int koff2 = r * 128 + (((2 * 2 + h) ^ ksw) << 4);
+  const int koff3 = r * 128 + (((3 * 2 + h) ^ ksw) << 4);
+  // V^T fragment via ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its block;
+  // rows 4h + tq (+16sp + 32t), 64-byte half (dt ^ ((row>>1)&1)), (row>>1)&1 == (tq>>1)&1
   const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, g16 = (lane >> 4) & 1;
+  const int vsw = (tq >> 1) & 1;
+  const int vlane = (4 * h + tq) * 128 + (g16 * 2 + (tp >> 1)) * 16 + (tp & 1) * 8;
+  const int voff_d0 = vlane + (vsw ? 64 : 0);   // dt = 0
+  const int voff_d1 = vlane + (vsw ? 0 : 64);   // dt = 1
+  const char* const kbase_lds = reinterpret_cast<const char*>(&kl[0][0]);
+  const char* const vbase_lds = reinterpret_cast<const char*>(&vl[0][0]);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
   GLOAD(0);
@@ -90,20 +105,21 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) GLOAD(kt + 1);
+    const char* kt_lds = kbase_lds + buf * (KB * 128);
+    const char* vt_lds = vbase_lds + buf * (KB * 128);
 
     // ---- S^T = K Q^T (64 keys x 32 queries per wave) ----
     f32x16 s_acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s_acc[t][e] = 0.f;
-      const int key = t * 32 + r;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int chunk = ks * 2 + h;
-        const bf16x8 kf = __builtin_bit_cast(bf16x8, kl[buf][key * 8 + (chunk ^ ((key >> 1) & 7))]);
-        s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[t], 0, 0, 0);
-      }
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kt_lds + koff0 + t * 4096);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kt_lds + koff1 + t * 4096);
+      const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kt_lds + koff2 + t * 4096);
+      const bf16x8 k3 = *reinterpret_cast<const bf16x8*>(kt_lds + koff3 + t * 4096);
+      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], zero16, 0, 0, 0);
+      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], s_acc[t], 0, 0, 0);
+      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[2], s_acc[t], 0, 0, 0);
+      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, qf[3], s_acc[t], 0, 0, 0);
     }
     // mask keys past the end of the sequence (last tile only)
     if (kt * KB + KB > S) {
@@ -123,7 +139,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s_acc[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
     const float mc = m_new * c_exp;
     float psum = 0.f;
 #pragma unroll
@@ -133,6 +148,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
         s_acc[t][e] = __builtin_amdgcn_exp2f(fmaf(s_acc[t][e], c_exp, -mc));
         psum += s_acc[t][e];
       }
+    // rescale the running state only when some row's max moved (wave-uniform branch; exact: alpha == 1 otherwise)
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+      m_run = m_new;
+    }
+    l_run += psum;
     // P as bf16 B-operand fragments: k-step (t, sp) = registers 8sp..8sp+7 of score tile t
 #define PFRAG(t_, sp_)                                                                                             \
   ((bf16x8){(bf16_t)s_acc[t_][8 * sp_ + 0], (bf16_t)s_acc[t_][8 * sp_ + 1], (bf16_t)s_acc[t_][8 * sp_ + 2],        \
@@ -140,27 +166,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
             (bf16_t)s_acc[t_][8 * sp_ + 6], (bf16_t)s_acc[t_][8 * sp_ + 7]})
     const bf16x8 pf00 = PFRAG(0, 0), pf01 = PFRAG(0, 1), pf10 = PFRAG(1, 0), pf11 = PFRAG(1, 1);
 #undef PFRAG
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
 
     // ---- O^T += V^T P^T ----
-    const char* vtile = reinterpret_cast<const char*>(&vl[buf][0]);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-      const int chunk = dt * 4 + g16 * 2 + (tp >> 1);
+      const char* vb = vt_lds + (dt == 0 ? voff_d0 : voff_d1);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
-          const int row0 = t * 32 + sp * 16 + 4 * h + tq;
-          const int swz = ((row0 >> 1) & 1) << 2;  // same for row0 + 8
-          const int off0 = (row0 * 8 + (chunk ^ swz)) * 16 + (tp & 1) * 8;
-          const bf16x4 lo = lds_read_tr16(vtile + off0);
-          const bf16x4 hi = lds_read_tr16(vtile + off0 + 8 * 128);
+          const bf16x4 lo = lds_read_tr16(vb + t * 4096 + sp * 2048);
+          const bf16x4 hi = lds_read_tr16(vb + t * 4096 + sp * 2048 + 1024);
           const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           const bf16x8 pfr = t == 0 ? (sp == 0 ? pf00 : pf01) : (sp == 0 ? pf10 : pf11);
           o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfr, o_acc[dt], 0, 0, 0);

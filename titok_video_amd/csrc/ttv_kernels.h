@@ -58,3 +58,8 @@ bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 // ---- ttv_attn.hip ----
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
                    int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s);
+
+// ---- ttv_mlp.hip ----
+bool ttvk_mlp_fused_supported(int dtype, int width, int inner);
+int ttvk_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
+                   const float* post_gain, float alpha, float eps, int M, hipStream_t s);

@@ -143,6 +143,19 @@ class _WeightPack:
             keep.append(t)
             return t.data_ptr()
 
+        def w3_permuted(w):
+            """Columns of w3 reordered inside every 32-column panel to the k order of the fused feed-forward kernel
+            (csrc/ttv_mlp.hip): new[:, 32p + 8q + j] = old[:, 32p + (j < 4 ? 4q + j : 16 + 4q + (j - 4))]."""
+            if not fold or w.shape[1] % 32:
+                return None
+            q = torch.arange(4).view(4, 1)
+            j = torch.arange(8).view(1, 8)
+            within = torch.where(j < 4, 4 * q + j, 16 + 4 * q + (j - 4)).reshape(-1)            # [32]
+            cols = (torch.arange(w.shape[1] // 32).view(-1, 1) * 32 + within.view(1, -1)).reshape(-1).to(device)
+            t = w.detach().to(device=device, dtype=dtype)[:, cols].contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
         perm = tower._patch_perm().to(device)
         if tower.kind == _lib.TTV_ENCODER:
             w_in = tower.proj_in.weight.detach().to(device)[:, perm]
@@ -161,7 +174,8 @@ class _WeightPack:
                 ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
                 ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
-                to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight), w12_pn=folded(f.w12.weight, f.norm.weight))
+                to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight), w12_pn=folded(f.w12.weight, f.norm.weight),
+                w3_perm=w3_permuted(f.w3.weight))
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
