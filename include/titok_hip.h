@@ -104,7 +104,9 @@ int ttv_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
  * Non-causal, block-diagonal over cu_seqlens (device int32 [n_seq+1]), GQA, softmax scale head_dim^-0.5.
- * qblocks: device int32 [n_qblocks,2] = (sequence id, first query row within the sequence), 128 rows per block.
+ * qblocks: device int32 [n_qblocks,4] work table = (sequence id, first query row within the sequence, q-head, 0), one
+ * entry per 128-query block per q-head; sequence id -1 = padding.  The host orders it so that entries i, i+8, i+16, ...
+ * (one XCD under round-robin dispatch) share a (sequence, kv-head): its K/V are then fetched into one L2 only.
  * If gate_mul == 0 the raw attention output is written. */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream);
@@ -177,7 +179,7 @@ typedef struct ttv_batch {
   const int32_t* latent_rows;  /* [sum_tokens]  packed row of every latent token, clip-major */
   const int32_t* patch_rows;   /* [sum_patches] packed row of every patch token, clip-major */
   const int32_t* clip_desc;    /* [n_clips,8] see ttv_patch_gather */
-  const int32_t* qblocks;      /* [n_qblocks,2] see ttv_attention */
+  const int32_t* qblocks;      /* [n_qblocks,4] see ttv_attention (built for this tower's head counts) */
   const float* rope_cs;        /* [L,64] cos|sin, fp64-evaluated on the host as rope.py:48-54 */
 } ttv_batch;
 

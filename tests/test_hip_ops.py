@@ -286,8 +286,9 @@ def test_attention_varlen_gqa_gate(dt, case, heads):
     out = torch.empty(plan.total_rows, d, dtype=DT[dt], device=DEV)
     xd = qkvg.to(DEV)
     for gate in (1, 0):
-        _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(),
-                                     plan.n_qblocks, hq, hkv, 64, gate, _lib.dtype_code(DT[dt]), S()), "attention")
+        tab = plan.attention_table(hq, hkv)
+        _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
+                                     tab.shape[0], hq, hkv, 64, gate, _lib.dtype_code(DT[dt]), S()), "attention")
         f = qkvg.float()
         q, gt, k, v = f.split([d, d, gq, gq], dim=-1)
         ref = O.attention_varlen(q.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)),
@@ -310,8 +311,9 @@ def test_attention_online_softmax_rescale_branch():
     x = x.to(torch.bfloat16)
     out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
     xd = x.to(DEV)
-    _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(),
-                                 plan.n_qblocks, hq, hkv, 64, 0, _lib.TTV_BF16, S()), "attention")
+    tab = plan.attention_table(hq, hkv)
+    _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
+                                 tab.shape[0], hq, hkv, 64, 0, _lib.TTV_BF16, S()), "attention")
     f = x.float()
     qq, gt, k, v = f.split([d, d, gq, gq], dim=-1)
     ref = O.attention_varlen(qq.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)

@@ -210,7 +210,7 @@ def test_blocks_kat_fp32():
     qkv = torch.empty(Lr, 2 * dm + 2 * gq, device=DEV)
     _lib.check(lib.ttv_linear_qkv_rope(xn.data_ptr(), dm, w[p + "attn_layer.1.to_qkv.weight"].data_ptr(), dm, qkv.data_ptr(), 2 * dm + 2 * gq, Lr, dm, gq, plan.rope_cs.data_ptr(), 1, S), "q")
     ao = torch.empty(Lr, dm, device=DEV)
-    _lib.check(lib.ttv_attention(qkv.data_ptr(), 2 * dm + 2 * gq, ao.data_ptr(), dm, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(), plan.n_qblocks, 4, 2, 64, 1, 1, S), "a")
+    _lib.check(lib.ttv_attention(qkv.data_ptr(), 2 * dm + 2 * gq, ao.data_ptr(), dm, plan.cu_dev.data_ptr(), plan.attention_table(4, 2).data_ptr(), plan.attention_table(4, 2).shape[0], 4, 2, 64, 1, 1, S), "a")
     out = torch.empty(Lr, dm, device=DEV)
     _lib.check(lib.ttv_linear(ao.data_ptr(), dm, w[p + "attn_layer.1.out_proj.weight"].data_ptr(), dm, None, None, out.data_ptr(), dm, Lr, dm, dm, 1, S), "o")
     np.testing.assert_allclose(out.cpu().numpy(), d["attn1"], rtol=1e-3, atol=1e-3)

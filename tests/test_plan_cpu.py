@@ -26,13 +26,20 @@ def test_plan_tables_match_oracle_metadata():
     rows = torch.arange(len(mask))
     assert plan.latent_rows_dev.tolist() == rows[mask].tolist()
     assert plan.patch_rows_dev.tolist() == rows[~mask].tolist()
-    qb = plan.qblocks_dev.view(-1, 2).tolist()
-    covered = []
-    for b, q0 in qb:
-        s = cu[b + 1] - cu[b]
-        assert q0 % 128 == 0 and q0 < s
-        covered += [(b, r) for r in range(q0, min(q0 + 128, s))]
-    assert len(covered) == cu[-1] == len(set(covered))
+    for hq, hkv in [(4, 2), (12, 4)]:
+        tab = plan.attention_table(hq, hkv).tolist()
+        covered = []
+        unit_xcd = {}
+        for i, (b, q0, head, _) in enumerate(tab):
+            if b < 0:
+                continue                                   # padding entry of the XCD-interleaved order
+            s_len = cu[b + 1] - cu[b]
+            assert q0 % 128 == 0 and q0 < s_len and 0 <= head < hq
+            covered += [(b, head, r) for r in range(q0, min(q0 + 128, s_len))]
+            unit = (b, head // (hq // hkv))
+            assert unit_xcd.setdefault(unit, i % 8) == i % 8    # all blocks sharing K/V sit on one XCD slot
+        assert len(covered) == cu[-1] * hq == len(set(covered))   # every (row, q-head) exactly once
+        assert plan.batch_for(hq, hkv).n_qblocks == len(tab)
     desc = plan.clip_desc_dev.view(-1, 8)
     assert desc[:, 6].tolist() == [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]
 

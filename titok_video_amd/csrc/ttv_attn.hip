@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y;
-  const int seq = qblocks[2 * blockIdx.x], q0 = qblocks[2 * blockIdx.x + 1];
+  // work table entry: (sequence, first query row, q-head); sequence < 0 = padding entry of the XCD-interleaved order
+  const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
+  if (seq < 0) return;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int kvh = head / rep;
   const bf16_t* qbase = qkvg + (size_t)s0 * ld + head * 64;
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
   float* vs = ks + KB * 65;            // [64][64]
   float* ps = vs + KB * 64;            // [4][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int head = blockIdx.y;
-  const int seq = qblocks[2 * blockIdx.x], q0 = qblocks[2 * blockIdx.x + 1];
+  const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
+  if (seq < 0) return;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int kvh = head / rep;
   const float* qbase = qkvg + (size_t)s0 * ld + head * 64;
@@ -298,7 +299,7 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   const int d_model = q_heads * 64, gqa = kv_heads * 64, rep = q_heads / kv_heads;
   TTV_CHECK_ARG(ld >= 2 * d_model + 2 * gqa && ld % 8 == 0 && ldo % 4 == 0, "attention: bad leading dims");
   TTV_CHECK_ARG((uintptr_t)qkvg % 16 == 0 && (uintptr_t)out % 8 == 0, "attention: unaligned pointers");
-  dim3 grid(n_qblocks, q_heads);
+  dim3 grid(n_qblocks);   // one entry per (sequence, 128-query block, q-head), XCD-interleaved by the host
   const float scale = 0.125f;  // 64^-0.5
   TtvProfScope prof(TTV_KC_ATTENTION, s);
   if (dtype == TTV_BF16) {

@@ -337,8 +337,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
-  const int it0 = (int)((long)total_items * blockIdx.x / gridDim.x);
-  const int it1 = (int)((long)total_items * (blockIdx.x + 1) / gridDim.x);
+  // consecutive logical blocks share token tiles; keep them on one XCD (same L2) under round-robin dispatch
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int it0 = (int)((long)total_items * lb / gridDim.x);
+  const int it1 = (int)((long)total_items * (lb + 1) / gridDim.x);
   if (it0 >= it1) return;
 
   const bf16_t* W = (const bf16_t*)p.w;

@@ -101,7 +101,7 @@ class _Tower(nn.Module):
                               alpha=float(self.model_layers.alpha))
 
     def _workspace(self, dims: _lib.TowerDims, plan: BatchPlan, device) -> torch.Tensor:
-        need = _lib.lib().ttv_tower_workspace_bytes(C.byref(dims), C.byref(plan.batch))
+        need = _lib.lib().ttv_tower_workspace_bytes(C.byref(dims), C.byref(plan.batch_for(self.heads[0], self.heads[1])))
         if need < 0:
             _lib.check(1, "ttv_tower_workspace_bytes")
         key = (str(device), dims.dtype)
@@ -225,8 +225,9 @@ class TiTokEncoder(_Tower):
             indices = torch.empty((n,), dtype=torch.int32, device=device)
             if want_bounded:
                 bounded = torch.empty((n, c), dtype=torch.float32, device=device)
+        batch = plan.batch_for(self.heads[0], self.heads[1])
         rc = _lib.lib().ttv_encoder_forward(
-            C.byref(dims), C.byref(pack.struct), C.byref(plan.batch), _lib.ptr_array(clips),
+            C.byref(dims), C.byref(pack.struct), C.byref(batch), _lib.ptr_array(clips),
             C.byref(fsq_params) if fsq_params is not None else None, _lib.ptr(z), _lib.ptr(codes), _lib.ptr(indices),
             _lib.ptr(bounded), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_encoder_forward")
@@ -273,7 +274,8 @@ class TiTokDecoder(_Tower):
         for (t, h, w), n in zip(pix, sizes):
             outs.append(flat[off:off + n].view(self.out_channels, t, h, w))
             off += n
-        rc = _lib.lib().ttv_decoder_forward(C.byref(dims), C.byref(pack.struct), C.byref(plan.batch), tokens.data_ptr(),
+        batch = plan.batch_for(self.heads[0], self.heads[1])
+        rc = _lib.lib().ttv_decoder_forward(C.byref(dims), C.byref(pack.struct), C.byref(batch), tokens.data_ptr(),
                                             _lib.ptr_array(outs), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_decoder_forward")
         return outs

@@ -88,15 +88,7 @@ class BatchPlan:
             T, H, W = self.pixel_grids[b]
             desc[b] = (T, H, W, grids[b][0], grids[b][1], grids[b][2], pbase, 3)
             pbase += sizes[b]
-        qb = []
-        for b in range(B):
-            s = cu[b + 1] - cu[b]
-            for q0 in range(0, s, QBLOCK):
-                qb.append((b, q0))
-        qblocks = np.asarray(qb, dtype=np.int32).reshape(-1, 2)
-        self.n_qblocks = qblocks.shape[0]
-
-        parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1), qblocks.reshape(-1)]
+        parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1)]
         offs, total = [], 0
         for p in parts:
             offs.append(total)
@@ -109,12 +101,49 @@ class BatchPlan:
         self.rope_cs = torch.from_numpy(rope).to(self.device)
 
         base = self.int_tables.data_ptr()
-        self.batch = _lib.Batch(
+        self._base_fields = dict(
             n_clips=B, total_rows=self.total_rows, sum_tokens=self.sum_tokens, sum_patches=self.sum_patches,
-            max_patches_per_clip=max(sizes), n_qblocks=self.n_qblocks,
+            max_patches_per_clip=max(sizes),
             cu_seqlens=base + 4 * offs[0], latent_rows=base + 4 * offs[1], patch_rows=base + 4 * offs[2],
-            clip_desc=base + 4 * offs[3], qblocks=base + 4 * offs[4], rope_cs=self.rope_cs.data_ptr())
+            clip_desc=base + 4 * offs[3], rope_cs=self.rope_cs.data_ptr())
         self._offs = offs
+        self._attn = {}
+
+    def attention_table(self, q_heads: int, kv_heads: int) -> torch.Tensor:
+        """int32 [n,4] attention work table (sequence, first query row, q-head, 0) for this batch, XCD-aware.
+
+        Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8 share an XCD - a speed
+        assumption only, never correctness).  All blocks of one (sequence, kv-head) unit re-read the same K/V, so units
+        are distributed over 8 lists (greedy by block count) and the lists are interleaved: entry i goes to list i % 8.
+        Shorter lists are padded with sequence = -1 entries (the kernel returns immediately)."""
+        key = (int(q_heads), int(kv_heads))
+        t = self._attn.get(key)
+        if t is None:
+            rep = q_heads // kv_heads
+            units = []
+            for b in range(len(self.grids)):
+                s = self.cu_seqlens[b + 1] - self.cu_seqlens[b]
+                for kvh in range(kv_heads):
+                    units.append([(b, q0, kvh * rep + r, 0) for q0 in range(0, s, QBLOCK) for r in range(rep)])
+            lists = [[] for _ in range(8)]
+            for u in sorted(units, key=len, reverse=True):
+                min(lists, key=len).extend(u)
+            depth = max(len(l) for l in lists)
+            table = np.full((depth, 8, 4), -1, dtype=np.int32)
+            for x, l in enumerate(lists):
+                if l:
+                    table[: len(l), x, :] = np.asarray(l, dtype=np.int32)
+            # drop trailing all-padding rows only (interior padding keeps the i % 8 alignment)
+            flat = table.reshape(-1, 4)
+            last = int(np.max(np.nonzero(flat[:, 0] >= 0)[0])) + 1
+            t = torch.from_numpy(np.ascontiguousarray(flat[:last])).to(self.device)
+            self._attn[key] = t
+        return t
+
+    def batch_for(self, q_heads: int, kv_heads: int) -> "_lib.Batch":
+        """ttv_batch struct whose attention work table matches the tower's head counts."""
+        t = self.attention_table(q_heads, kv_heads)
+        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), **self._base_fields)
 
     # views used by tests that call single ops
     def table(self, i: int, n: int) -> torch.Tensor:
@@ -136,9 +165,6 @@ class BatchPlan:
     def clip_desc_dev(self):
         return self.table(3, 8 * len(self.grids))
 
-    @property
-    def qblocks_dev(self):
-        return self.table(4, 2 * self.n_qblocks)
 
 
 _plan_cache = {}

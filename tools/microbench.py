@@ -87,7 +87,7 @@ for dbg in ([0, 1] if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
     timeit("linear K256 N768 (k256, dec proj_out)", lambda: lib.ttv_linear(x.data_ptr(), d, wpo.data_ptr(), d, None, None, big.data_ptr(), 768, 32768, 768, d, 0, S),
            2.0 * 32768 * 768 * d, 32768 * (768 + d) * 2)
 lib.ttv_debug_set(0)
-timeit("attention (gate)", lambda: lib.ttv_attention(qkv_in.data_ptr(), 768, ao.data_ptr(), d, plan.cu_dev.data_ptr(), plan.qblocks_dev.data_ptr(), plan.n_qblocks, 4, 2, 64, 1, 0, S),
+timeit("attention (gate)", lambda: lib.ttv_attention(qkv_in.data_ptr(), 768, ao.data_ptr(), d, plan.cu_dev.data_ptr(), plan.attention_table(4, 2).data_ptr(), plan.attention_table(4, 2).shape[0], 4, 2, 64, 1, 0, S),
        32 * 4.0 * 1152 * 1152 * d)
 timeit("rmsnorm bf16->bf16", lambda: lib.ttv_rmsnorm(x.data_ptr(), 0, d, None, yb.data_ptr(), 0, d, None, gain.data_ptr(), L, d, 1e-5, S), None, L * d * 4)
 timeit("rmsnorm f32->bf16", lambda: lib.ttv_rmsnorm(y32.data_ptr(), 1, d, None, yb.data_ptr(), 0, d, None, gain.data_ptr(), L, d, 1e-5, S), None, L * d * 6)
