@@ -181,6 +181,10 @@ typedef struct ttv_batch {
   const int32_t* clip_desc;    /* [n_clips,8] see ttv_patch_gather */
   const int32_t* qblocks;      /* [n_qblocks,4] see ttv_attention (built for this tower's head counts) */
   const float* rope_cs;        /* [L,64] cos|sin, fp64-evaluated on the host as rope.py:48-54 */
+  /* training only (may be NULL for inference): */
+  const int32_t* blocks64;     /* [n_blocks64,2] (sequence, first row) of every 64-row block (attention backward) */
+  const int32_t* row_seq;      /* [L] sequence id of every packed row */
+  int32_t n_blocks64;
 } ttv_batch;
 
 /* bytes of scratch a tower forward needs for this batch */
@@ -198,6 +202,67 @@ int ttv_encoder_forward(const ttv_tower_dims* dims, const ttv_tower_weights* w, 
  * (HOST array of device ptrs to [C,T,H,W] buffers, dtype). */
 int ttv_decoder_forward(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_batch* batch, const void* codes,
                         void* const* clips_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- training step: tape-recording forward + backward (reference train.py:65-83 = autograd through the towers) ------- */
+/* Transposed linear weights for the data-gradient GEMMs (dX = dY W is run as dY (W^T)^T), compute dtype. */
+typedef struct ttv_layer_weights_t {
+  const void* to_qkv_t;    /* [d, 2d+2g]  */
+  const void* out_proj_t;  /* [d, d]      */
+  const void* w12_t;       /* [d, 2I]     */
+  const void* w3_t;        /* [I, d]      */
+} ttv_layer_weights_t;
+typedef struct ttv_tower_weights_t {
+  const void* proj_in_t;   /* encoder: [C*pt*ph*pw, d] (packed order); decoder: unused (NULL) */
+  const void* proj_out_t;  /* decoder: [d, C*pt*ph*pw] (packed order); encoder: unused (NULL) */
+  const ttv_layer_weights_t* layers;   /* HOST array [layers] */
+} ttv_tower_weights_t;
+/* fp32 gradient buffers, same shapes/layout as the PACKED weights of ttv_tower_weights; zeroed by the caller, accumulated into. */
+typedef struct ttv_layer_grads {
+  float* pre_ln; float* to_qkv; float* out_proj; float* ffd_norm; float* w12; float* w3; float* attn_post_ln; float* ffd_post_ln;
+} ttv_layer_grads;
+typedef struct ttv_tower_grads {
+  float* proj_in_w; float* proj_in_b; float* mask_token; float* ln_pre_t; float* ln_pre_p; float* ln_post; float* proj_out_w;
+  float* proj_out_b;
+  const ttv_layer_grads* layers;       /* HOST array [layers] */
+} ttv_tower_grads;
+
+int64_t ttv_tower_tape_bytes(const ttv_tower_dims* dims, const ttv_batch* batch);
+int64_t ttv_tower_bwd_workspace_bytes(const ttv_tower_dims* dims, const ttv_batch* batch);
+/* TiTokEncoder.forward recording a tape; z fp32 [sum_tokens, token_size] (FSQ is a separate differentiable op). */
+int ttv_encoder_forward_train(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_batch* batch, const void* const* clips,
+                              float* z, void* tape, int64_t tape_bytes, void* stream);
+/* Backward of the above: dz fp32 -> parameter gradients (accumulated) and, if dclips != NULL, gradients w.r.t. the input
+ * clips (HOST array of device ptrs, compute dtype; needed by the discriminator path, loss_module.py:149-152). */
+int ttv_encoder_backward(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* batch,
+                         const float* dz, void* tape, const ttv_tower_grads* grads, void* const* dclips, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+/* TiTokDecoder.forward recording a tape (workspace >= sum_patches * C*pt*ph*pw elements). */
+int ttv_decoder_forward_train(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_batch* batch, const void* codes,
+                              void* const* clips_out, void* tape, int64_t tape_bytes, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+/* Backward: dclips_out (HOST array of device ptrs to d loss / d reconstruction, compute dtype) -> parameter gradients and
+ * dcodes fp32 [sum_tokens, token_size] (may be NULL). */
+int ttv_decoder_backward(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* batch,
+                         const void* codes, const void* const* dclips_out, void* tape, const ttv_tower_grads* grads, float* dcodes,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+/* Straight-through FSQ backward (fsq.py:48-51,78-90): dz = dcodes * half_l/half_width * (1 - tanh^2(z + shift)). */
+int ttv_fsq_backward(const ttv_fsq_params* p, const float* z, const void* dcodes, int dcodes_dtype, float* dz, int rows, void* stream);
+
+/* Single backward ops, exported for parity tests. */
+/* dW[N,K] (fp32, accumulated) += dY[L,N]^T X[L,K]  (weight gradient of y = x w^T). */
+int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype, void* stream);
+/* RMSNorm backward: dx (dtype), dgain fp32 [width] (accumulated; may be NULL). */
+int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const float* gain, void* dx, int lddx, float* dgain, int rows,
+                         int width, float eps, int dtype, void* stream);
+/* Attention backward (flash-style recompute from the forward's LSE): qkvg as in ttv_attention, o / dout [L,d], lse fp32
+ * [L,q_heads] -> dqkvg [L,2d+2g] (q, k, v column ranges written; gate range untouched).  delta: fp32 [L,q_heads] scratch;
+ * dkv_scratch: fp32 [L,2g] scratch (fp32 dtype only). blocks64 / row_seq as in ttv_batch. */
+int ttv_attention_backward(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
+                           const int32_t* cu_seqlens, const int32_t* blocks64, int n_blocks64, const int32_t* row_seq, void* dqkvg,
+                           int ldg, float* dkv_scratch, int total_rows, int q_heads, int kv_heads, int dtype, void* stream);
+/* ttv_attention with an extra fp32 [L,q_heads] log-sum-exp output (training forward). */
+int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
+                      int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, float* lse, void* stream);
 
 /* ---- codebook statistics (train_utils/codebook_logging.py:19-32) -------------------------------------- */
 /* counts[idx] += 1 for every index (int64 device histogram, atomics); usage/entropy are finished on the host. */

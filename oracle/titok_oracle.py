@@ -290,7 +290,7 @@ def fsq_forward(z: Tensor, levels: Sequence[int]):
     lv, basis = fsq_tables(levels)
     zf = z.float()
     bounded = fsq_bound(zf, levels)
-    q = bounded.round()                      # round_ste forward value, fsq.py:48-51
+    q = bounded + (bounded.round() - bounded).detach()   # round_ste (fsq.py:48-51): round forward, identity backward
     half_width = lv // 2
     codes = q / half_width                   # fsq.py:85-90
     zhat = codes * half_width + half_width   # fsq.py:92-94

@@ -45,11 +45,13 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.TowerDims) == 15 * 4
     assert C.sizeof(_lib.LayerWeights) == 11 * 8
     assert C.sizeof(_lib.TowerWeights) == 9 * 8
-    assert C.sizeof(_lib.Batch) == 6 * 4 + 6 * 8
+    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 8   # + blocks64, row_seq, n_blocks64 (padded)
     src = open(HEADER).read()
     for struct, cls in [("ttv_fsq_params", _lib.FsqParams), ("ttv_tower_dims", _lib.TowerDims),
                         ("ttv_layer_weights", _lib.LayerWeights), ("ttv_tower_weights", _lib.TowerWeights),
-                        ("ttv_batch", _lib.Batch)]:
+                        ("ttv_batch", _lib.Batch), ("ttv_layer_weights_t", _lib.LayerWeightsT),
+                        ("ttv_tower_weights_t", _lib.TowerWeightsT), ("ttv_layer_grads", _lib.LayerGrads),
+                        ("ttv_tower_grads", _lib.TowerGrads)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

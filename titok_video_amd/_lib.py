@@ -47,7 +47,26 @@ class TowerWeights(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("n_clips", i32), ("total_rows", i32), ("sum_tokens", i32), ("sum_patches", i32),
                 ("max_patches_per_clip", i32), ("n_qblocks", i32), ("cu_seqlens", vp), ("latent_rows", vp),
-                ("patch_rows", vp), ("clip_desc", vp), ("qblocks", vp), ("rope_cs", vp)]
+                ("patch_rows", vp), ("clip_desc", vp), ("qblocks", vp), ("rope_cs", vp), ("blocks64", vp), ("row_seq", vp),
+                ("n_blocks64", i32)]
+
+
+class LayerWeightsT(C.Structure):
+    _fields_ = [("to_qkv_t", vp), ("out_proj_t", vp), ("w12_t", vp), ("w3_t", vp)]
+
+
+class TowerWeightsT(C.Structure):
+    _fields_ = [("proj_in_t", vp), ("proj_out_t", vp), ("layers", C.POINTER(LayerWeightsT))]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
+                ("attn_post_ln", vp), ("ffd_post_ln", vp)]
+
+
+class TowerGrads(C.Structure):
+    _fields_ = [("proj_in_w", vp), ("proj_in_b", vp), ("mask_token", vp), ("ln_pre_t", vp), ("ln_pre_p", vp), ("ln_post", vp),
+                ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerGrads))]
 
 
 _lib = None
@@ -79,6 +98,22 @@ SYMBOLS = {
                                       C.POINTER(FsqParams), vp, vp, vp, vp, vp, i64, vp]),
     "ttv_decoder_forward": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(Batch), vp, C.POINTER(vp),
                                       vp, i64, vp]),
+    "ttv_tower_tape_bytes": (i64, [C.POINTER(TowerDims), C.POINTER(Batch)]),
+    "ttv_tower_bwd_workspace_bytes": (i64, [C.POINTER(TowerDims), C.POINTER(Batch)]),
+    "ttv_encoder_forward_train": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(Batch), C.POINTER(vp), vp, vp,
+                                            i64, vp]),
+    "ttv_encoder_backward": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(TowerWeightsT), C.POINTER(Batch), vp,
+                                       vp, C.POINTER(TowerGrads), C.POINTER(vp), vp, i64, vp]),
+    "ttv_decoder_forward_train": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(Batch), vp, C.POINTER(vp), vp,
+                                            i64, vp, i64, vp]),
+    "ttv_decoder_backward": (C.c_int, [C.POINTER(TowerDims), C.POINTER(TowerWeights), C.POINTER(TowerWeightsT), C.POINTER(Batch), vp,
+                                       C.POINTER(vp), vp, C.POINTER(TowerGrads), vp, vp, i64, vp]),
+    "ttv_fsq_backward": (C.c_int, [C.POINTER(FsqParams), vp, vp, C.c_int, vp, C.c_int, vp]),
+    "ttv_linear_wgrad": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_rmsnorm_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
+    "ttv_attention_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_attention_lse": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ttv_debug_set": (C.c_int, [C.c_int]),
     "ttv_prof_begin": (C.c_int, [C.c_int, C.c_int]),

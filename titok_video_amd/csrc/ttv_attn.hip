@@ -29,7 +29,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 template <bool GATE>
 __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
                                                       const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model,
-                                                      int gqa, int rep, float c_exp /* scale*log2(e) */) {
+                                                      int gqa, int rep, float c_exp /* scale*log2(e) */, float* __restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) uint4 kl[2][KB * 8];
   __shared__ __attribute__((aligned(16))) uint4 vl[2][KB * 8];
 
@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = 1.0f / l_tot;
+  if (lse_out && qrow < S && h == 0)   // natural-log LSE of the scaled scores (training tape): scale*max + ln(sum)
+    lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run * (c_exp * 0.69314718055994530942f) + __logf(l_tot);
   if (qrow < S) {
     bf16_t* orow = out + (size_t)(s0 + qrow) * ldo + head * 64;
     const bf16_t* grow = gbase + (size_t)qrow * ld;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
 template <bool GATE>
 __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
                                                   const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
-                                                  int rep, float scale) {
+                                                  int rep, float scale, float* __restrict__ lse_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qs = smem;                    // [128][64]
   float* ks = qs + QB * 64;            // [64][65]
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
 #pragma unroll
   for (int qi = 0; qi < 32; ++qi) {
     const int qrow = q0 + wave * 32 + qi;
+    if (lse_out && qrow < S && lane == 0) lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run[qi] + logf(l_run[qi]);
     if (qrow < S) {
       float v = o[qi] / l_run[qi];
       if (GATE) {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
 }
 
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
-                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s) {
+                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s, float* lse_out) {
   if (n_qblocks == 0) return TTV_OK;
   TTV_CHECK_ARG(head_dim == 64, "attention: head_dim %d unsupported (the reference fixes 64, utils.py:8)", head_dim);
   TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention: q_heads %% kv_heads");
@@ -304,16 +307,16 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   TtvProfScope prof(TTV_KC_ATTENTION, s);
   if (dtype == TTV_BF16) {
     const float c_exp = scale * 1.44269504088896340736f;
-    if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
-    else hipLaunchKernelGGL((k_attn_bf16<false>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
+    if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
+    else hipLaunchKernelGGL((k_attn_bf16<false>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
   } else if (dtype == TTV_F32) {
     const size_t smem = (QB * 64 + KB * 65 + KB * 64 + 4 * 64) * sizeof(float);
     if (gate_mul) {
       (void)hipFuncSetAttribute((const void*)k_attn_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale);
+      hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale, lse_out);
     } else {
       (void)hipFuncSetAttribute((const void*)k_attn_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL((k_attn_f32<false>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale);
+      hipLaunchKernelGGL((k_attn_f32<false>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale, lse_out);
     }
   } else {
     ttv_set_error("attention: bad dtype");

@@ -1,0 +1,863 @@
+// Backward kernels of the TiTok-Video towers (training step, reference train.py:65-83 runs autograd through
+// model/base/blocks.py + transformer.py + fsq.py; these kernels are that backward written by hand).
+//
+//   k_rmsnorm_bwd      dx, dgain of y = x * rsqrt(mean(x^2)+eps) * gain, with row gather/scatter maps
+//   k_colsum           bias gradients (sum over rows)
+//   k_gate_fwd/_bwd    a * sigmoid(gate)                                       (transformer.py:103)
+//   k_geglu_fwd/_bwd   gelu_erf(u_g) * u_x                                     (transformer.py:51-52)
+//   k_fsq_bwd          straight-through round: dz = dcodes * half_l/half_width * (1 - tanh^2(z+shift))   (fsq.py:48-51,78-90)
+//   k_scale_cast       b = alpha * a (fp32), c = (T) a
+//   k_wgrad_bf16       dW[N,K] += dY[L,N]^T X[L,K]: contraction over TOKENS, so both MFMA operands are fetched with
+//                      ds_read_b64_tr_b16 (hardware transpose read) from row-major LDS tiles; split over token ranges,
+//                      fp32 atomic accumulation into dW (one 256-byte row segment per wave instruction)
+//   k_attn_delta       delta[t,h] = sum_d dO*O
+//   k_attn_bwd_dq / k_attn_bwd_dkv   flash-style recompute (P from Q,K and the forward's LSE): no atomics - one kernel
+//                      owns query blocks (dQ), the other key blocks (dK, dV); GQA heads of a group are summed in-kernel
+//   *_f32 variants     naive VALU kernels, used only to check gradients tightly in fp32
+#include "ttv_common.h"
+#include "ttv_kernels.h"
+
+#define BW_MAX_ITERS 4
+
+// ------------------------------------------------------------------------------------------------ rmsnorm backward
+template <typename TX, typename TG, typename TO>
+__global__ __launch_bounds__(256) void k_rmsnorm_bwd(const TX* __restrict__ x, int ldx, const int* __restrict__ x_rows,
+                                                     const TG* __restrict__ dy, int lddy, const int* __restrict__ dy_rows,
+                                                     const float* __restrict__ gain, TO* __restrict__ dx, int lddx,
+                                                     const int* __restrict__ dx_rows, int accumulate, float* __restrict__ dgain,
+                                                     int rows, int d, float eps, int rows_per_wave) {
+  __shared__ float red[4][1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float dg[BW_MAX_ITERS][4];
+#pragma unroll
+  for (int it = 0; it < BW_MAX_ITERS; ++it)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dg[it][e] = 0.f;
+  const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+  for (int r = r0; r < r0 + rows_per_wave && r < rows; ++r) {
+    const TX* px = x + (size_t)(x_rows ? x_rows[r] : r) * ldx;
+    const TG* pg = dy + (size_t)(dy_rows ? dy_rows[r] : r) * lddy;
+    f32x4 xv[BW_MAX_ITERS], gv[BW_MAX_ITERS];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < BW_MAX_ITERS; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < d) {
+        xv[it] = Vec4<TX>::load(px + c);
+        gv[it] = Vec4<TG>::load(pg + c);
+        ss += xv[it][0] * xv[it][0] + xv[it][1] * xv[it][1] + xv[it][2] * xv[it][2] + xv[it][3] * xv[it][3];
+      }
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+    float dot = 0.f;   // sum_f (dy*gain) * xhat
+#pragma unroll
+    for (int it = 0; it < BW_MAX_ITERS; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < d) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = xv[it][e] * rstd;
+          dg[it][e] += gv[it][e] * xh;
+          gv[it][e] *= g[e];
+          dot += gv[it][e] * xh;
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)d;
+    TO* pd = dx + (size_t)(dx_rows ? dx_rows[r] : r) * lddx;
+#pragma unroll
+    for (int it = 0; it < BW_MAX_ITERS; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < d) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[it][e] - xv[it][e] * rstd * dot);
+        if (accumulate) o += Vec4<TO>::load(pd + c);
+        Vec4<TO>::store(pd + c, o);
+      }
+    }
+  }
+  if (dgain) {
+#pragma unroll
+    for (int it = 0; it < BW_MAX_ITERS; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < d) *reinterpret_cast<f32x4*>(&red[wave][c]) = (f32x4){dg[it][0], dg[it][1], dg[it][2], dg[it][3]};
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dgain + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
+template <typename TX, typename TG, typename TO>
+static int launch_rms_bwd(const void* x, int ldx, const int* xr, const void* dy, int lddy, const int* dyr, const float* gain, void* dx,
+                          int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps, hipStream_t s) {
+  const int rpw = 8;
+  hipLaunchKernelGGL((k_rmsnorm_bwd<TX, TG, TO>), dim3(ttv_cdiv(rows, 4 * rpw)), dim3(256), 0, s, (const TX*)x, ldx, xr, (const TG*)dy,
+                     lddy, dyr, gain, (TO*)dx, lddx, dxr, acc, dgain, rows, d, eps, rpw);
+  TTV_CHECK_LAUNCH("rmsnorm_bwd");
+  return TTV_OK;
+}
+
+// x dtype, dy dtype, dx dtype codes: TTV_BF16 / TTV_F32
+int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void* dy, int dy_dt, int lddy, const int* dyr,
+                     const float* gain, void* dx, int dx_dt, int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps,
+                     hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "rmsnorm_bwd: width");
+#define RB(TX, TG, TO) return launch_rms_bwd<TX, TG, TO>(x, ldx, xr, dy, lddy, dyr, gain, dx, lddx, dxr, acc, dgain, rows, d, eps, s)
+  const int key = x_dt * 4 + dy_dt * 2 + dx_dt;
+  switch (key) {
+    case 0: RB(bf16_t, bf16_t, bf16_t);
+    case 1: RB(bf16_t, bf16_t, float);
+    case 2: RB(bf16_t, float, bf16_t);
+    case 3: RB(bf16_t, float, float);
+    case 4: RB(float, bf16_t, bf16_t);
+    case 5: RB(float, bf16_t, float);
+    case 6: RB(float, float, bf16_t);
+    case 7: RB(float, float, float);
+  }
+#undef RB
+  return TTV_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums (bias grads)
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ a, int lda, const int* __restrict__ rows_map, int rows, int n,
+                                                float* __restrict__ out, int rows_per_block) {
+  // thread -> column (grid.y tiles of 256 columns), block -> row range
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= n) return;
+  const int r0 = blockIdx.x * rows_per_block;
+  float acc = 0.f;
+  for (int r = r0; r < r0 + rows_per_block && r < rows; ++r) acc += Cvt<T>::to_f(a[(size_t)(rows_map ? rows_map[r] : r) * lda + c]);
+  atomicAdd(out + c, acc);
+}
+
+int ttvk_colsum(const void* a, int dt, int lda, const int* rows_map, int rows, int n, float* out, hipStream_t s) {
+  if (rows == 0 || n == 0) return TTV_OK;
+  const int rpb = 128;
+  dim3 grid(ttv_cdiv(rows, rpb), ttv_cdiv(n, 256));
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_colsum<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)a, lda, rows_map, rows, n, out, rpb);
+  else hipLaunchKernelGGL((k_colsum<float>), grid, dim3(256), 0, s, (const float*)a, lda, rows_map, rows, n, out, rpb);
+  TTV_CHECK_LAUNCH("colsum");
+  return TTV_OK;
+}
+
+// sum of ALL elements (mask_token gradient pieces): out[0] += scale * sum(a[rows, 0:n])
+template <typename T>
+__global__ __launch_bounds__(256) void k_sumall(const T* __restrict__ a, int lda, const int* __restrict__ rows_map, int rows, int n,
+                                                const float* __restrict__ colw, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const long total = (long)rows * n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    const float v = Cvt<T>::to_f(a[(size_t)(rows_map ? rows_map[r] : r) * lda + c]);
+    acc += colw ? v * colw[c] : v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, scale * (red[0] + red[1] + red[2] + red[3]));
+}
+
+int ttvk_sumall(const void* a, int dt, int lda, const int* rows_map, int rows, int n, const float* colw, float scale, float* out,
+                hipStream_t s) {
+  if (rows == 0 || n == 0) return TTV_OK;
+  long total = (long)rows * n;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_sumall<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a, lda, rows_map, rows, n, colw, scale, out);
+  else hipLaunchKernelGGL((k_sumall<float>), dim3(blocks), dim3(256), 0, s, (const float*)a, lda, rows_map, rows, n, colw, scale, out);
+  TTV_CHECK_LAUNCH("sumall");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// ag = a * sigmoid(gate)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gate_fwd(const T* __restrict__ a, int lda, const T* __restrict__ gate, int ldg, T* __restrict__ ag,
+                                                  int ldo, int rows, int d) {
+  const long total = (long)rows * (d / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / (d / 4);
+    const int c = (int)(i % (d / 4)) * 4;
+    const f32x4 av = Vec4<T>::load(a + r * lda + c), gv = Vec4<T>::load(gate + r * ldg + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = av[e] * sigmoidf_(gv[e]);
+    Vec4<T>::store(ag + r * ldo + c, o);
+  }
+}
+// da = dag * sigmoid(gate);  dgate = dag * a * sigmoid(gate) * (1 - sigmoid(gate))
+template <typename T>
+__global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ dag, int ldd, const T* __restrict__ a, int lda,
+                                                  const T* __restrict__ gate, int ldg, T* __restrict__ da, int ldda, T* __restrict__ dgate,
+                                                  int lddg, int rows, int d) {
+  const long total = (long)rows * (d / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / (d / 4);
+    const int c = (int)(i % (d / 4)) * 4;
+    const f32x4 dv = Vec4<T>::load(dag + r * ldd + c), av = Vec4<T>::load(a + r * lda + c), gv = Vec4<T>::load(gate + r * ldg + c);
+    f32x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sg = sigmoidf_(gv[e]);
+      o1[e] = dv[e] * sg;
+      o2[e] = dv[e] * av[e] * sg * (1.0f - sg);
+    }
+    Vec4<T>::store(da + r * ldda + c, o1);
+    Vec4<T>::store(dgate + r * lddg + c, o2);
+  }
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+// h = gelu(u[:, I:]) * u[:, :I]
+template <typename T>
+__global__ __launch_bounds__(256) void k_geglu_fwd(const T* __restrict__ u, int ldu, T* __restrict__ h, int ldh, int rows, int I) {
+  const long total = (long)rows * (I / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / (I / 4);
+    const int c = (int)(i % (I / 4)) * 4;
+    const f32x4 xv = Vec4<T>::load(u + r * ldu + c), gv = Vec4<T>::load(u + r * ldu + I + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gelu_f(gv[e]) * xv[e];
+    Vec4<T>::store(h + r * ldh + c, o);
+  }
+}
+// du[:, :I] = dh * gelu(u_g);  du[:, I:] = dh * u_x * gelu'(u_g)
+template <typename T>
+__global__ __launch_bounds__(256) void k_geglu_bwd(const T* __restrict__ u, int ldu, const T* __restrict__ dh, int lddh,
+                                                   T* __restrict__ du, int lddu, int rows, int I) {
+  const long total = (long)rows * (I / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / (I / 4);
+    const int c = (int)(i % (I / 4)) * 4;
+    const f32x4 xv = Vec4<T>::load(u + r * ldu + c), gv = Vec4<T>::load(u + r * ldu + I + c), dv = Vec4<T>::load(dh + r * lddh + c);
+    f32x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o1[e] = dv[e] * gelu_f(gv[e]);
+      o2[e] = dv[e] * xv[e] * gelu_grad_f(gv[e]);
+    }
+    Vec4<T>::store(du + r * lddu + c, o1);
+    Vec4<T>::store(du + r * lddu + I + c, o2);
+  }
+}
+// b = alpha * a (fp32 -> fp32, may alias), c = (T) a
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_cast(const float* __restrict__ a, float alpha, float* __restrict__ b, T* __restrict__ c, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4);
+    if (c) Vec4<T>::store(c + i * 4, v);
+    if (b) *reinterpret_cast<f32x4*>(b + i * 4) = alpha * v;
+  }
+}
+// out (fp32) = (float) in  [T -> f32 copy, e.g. cast grads]
+template <typename T>
+__global__ __launch_bounds__(256) void k_to_f32(const T* __restrict__ a, float* __restrict__ b, long n4, int accumulate) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = Vec4<T>::load(a + i * 4);
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(b + i * 4);
+    *reinterpret_cast<f32x4*>(b + i * 4) = v;
+  }
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+int ttvk_gate_fwd(const void* a, int lda, const void* gate, int ldg, void* ag, int ldo, int rows, int d, int dt, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  const int nb = ew_blocks((long)rows * d / 4);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_gate_fwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)gate, ldg, (bf16_t*)ag, ldo, rows, d);
+  else hipLaunchKernelGGL((k_gate_fwd<float>), dim3(nb), dim3(256), 0, s, (const float*)a, lda, (const float*)gate, ldg, (float*)ag, ldo, rows, d);
+  TTV_CHECK_LAUNCH("gate_fwd");
+  return TTV_OK;
+}
+int ttvk_gate_bwd(const void* dag, int ldd, const void* a, int lda, const void* gate, int ldg, void* da, int ldda, void* dgate, int lddg,
+                  int rows, int d, int dt, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  const int nb = ew_blocks((long)rows * d / 4);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_gate_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dag, ldd, (const bf16_t*)a, lda, (const bf16_t*)gate, ldg, (bf16_t*)da, ldda, (bf16_t*)dgate, lddg, rows, d);
+  else hipLaunchKernelGGL((k_gate_bwd<float>), dim3(nb), dim3(256), 0, s, (const float*)dag, ldd, (const float*)a, lda, (const float*)gate, ldg, (float*)da, ldda, (float*)dgate, lddg, rows, d);
+  TTV_CHECK_LAUNCH("gate_bwd");
+  return TTV_OK;
+}
+int ttvk_geglu_fwd(const void* u, int ldu, void* h, int ldh, int rows, int I, int dt, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  const int nb = ew_blocks((long)rows * I / 4);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_geglu_fwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)u, ldu, (bf16_t*)h, ldh, rows, I);
+  else hipLaunchKernelGGL((k_geglu_fwd<float>), dim3(nb), dim3(256), 0, s, (const float*)u, ldu, (float*)h, ldh, rows, I);
+  TTV_CHECK_LAUNCH("geglu_fwd");
+  return TTV_OK;
+}
+int ttvk_geglu_bwd(const void* u, int ldu, const void* dh, int lddh, void* du, int lddu, int rows, int I, int dt, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  const int nb = ew_blocks((long)rows * I / 4);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_geglu_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)u, ldu, (const bf16_t*)dh, lddh, (bf16_t*)du, lddu, rows, I);
+  else hipLaunchKernelGGL((k_geglu_bwd<float>), dim3(nb), dim3(256), 0, s, (const float*)u, ldu, (const float*)dh, lddh, (float*)du, lddu, rows, I);
+  TTV_CHECK_LAUNCH("geglu_bwd");
+  return TTV_OK;
+}
+int ttvk_scale_cast(const float* a, float alpha, float* b, void* c, int dt, long n, hipStream_t s) {
+  if (n == 0) return TTV_OK;
+  const int nb = ew_blocks(n / 4);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_scale_cast<bf16_t>), dim3(nb), dim3(256), 0, s, a, alpha, b, (bf16_t*)c, n / 4);
+  else hipLaunchKernelGGL((k_scale_cast<float>), dim3(nb), dim3(256), 0, s, a, alpha, b, (float*)c, n / 4);
+  TTV_CHECK_LAUNCH("scale_cast");
+  return TTV_OK;
+}
+int ttvk_to_f32(const void* a, int dt, float* b, long n, int accumulate, hipStream_t s) {
+  if (n == 0) return TTV_OK;
+  const int nb = ew_blocks(n / 4);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_to_f32<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)a, b, n / 4, accumulate);
+  else hipLaunchKernelGGL((k_to_f32<float>), dim3(nb), dim3(256), 0, s, (const float*)a, b, n / 4, accumulate);
+  TTV_CHECK_LAUNCH("to_f32");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ FSQ straight-through backward
+struct FsqBwdDev { int n; float k[TTV_MAX_FSQ], shift[TTV_MAX_FSQ]; };
+template <typename TG>
+__global__ __launch_bounds__(256) void k_fsq_bwd(FsqBwdDev p, const float* __restrict__ z, const TG* __restrict__ dcodes,
+                                                 float* __restrict__ dz, int rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * p.n) return;
+  const int c = i % p.n;
+  const float t = tanhf(z[i] + p.shift[c]);
+  dz[i] = Cvt<TG>::to_f(dcodes[i]) * p.k[c] * (1.0f - t * t);
+}
+int ttvk_fsq_bwd(const ttv_fsq_params* fp, const float* z, const void* dcodes, int dt, float* dz, int rows, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  FsqBwdDev p;
+  p.n = fp->n;
+  for (int i = 0; i < TTV_MAX_FSQ; ++i) {
+    p.k[i] = i < fp->n ? fp->half_l[i] / fp->half_width[i] : 0.f;
+    p.shift[i] = fp->shift[i];
+  }
+  const int nb = ttv_cdiv(rows * fp->n, 256);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_fsq_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, p, z, (const bf16_t*)dcodes, dz, rows);
+  else hipLaunchKernelGGL((k_fsq_bwd<float>), dim3(nb), dim3(256), 0, s, p, z, (const float*)dcodes, dz, rows);
+  TTV_CHECK_LAUNCH("fsq_bwd");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient GEMM
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_b;
+__device__ __forceinline__ bf16x4 tr16(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)p); }
+
+// dW[N,K] (fp32, accumulated with atomics) += dY[L,N]^T X[L,K].  Block: 64 x 64 outputs, one token range (blockIdx.z).
+// LDS tiles are row-major [64 tokens][64 cols] bf16 (128-byte rows); a fragment of 8 consecutive TOKENS for one column is
+// two transposed reads of 4 tokens (lane 4q+p of a 16-lane group addresses token row q, columns 4p..4p+3).
+__global__ __launch_bounds__(256) void k_wgrad_bf16(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                    float* __restrict__ dw, int lddw, int L, int N, int K, int tokens_per_block) {
+  __shared__ __attribute__((aligned(16))) uint4 ay[64 * 8];
+  __shared__ __attribute__((aligned(16))) uint4 ax[64 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int t_begin = blockIdx.z * tokens_per_block;
+  const int t_end = min(L, t_begin + tokens_per_block);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // staging: 512 chunks per tile, 2 per thread: token = (tid>>3) + 32*i, 16-byte chunk = tid & 7
+  const int srow = tid >> 3, sc = tid & 7;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  const int gi = l15, tq = gi >> 2, tp = gi & 3;
+  for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = t0 + srow + 32 * i;
+      const bool ok = t < t_end;
+      const int cn = n0 + sc * 8, ck = k0 + sc * 8;
+      ay[(srow + 32 * i) * 8 + sc] = (ok && cn < N) ? *reinterpret_cast<const uint4*>(dy + (size_t)t * lddy + cn) : zero4;
+      ax[(srow + 32 * i) * 8 + sc] = (ok && ck < K) ? *reinterpret_cast<const uint4*>(x + (size_t)t * ldx + ck) : zero4;
+    }
+    __syncthreads();
+    const char* by = reinterpret_cast<const char*>(ay);
+    const char* bx = reinterpret_cast<const char*>(ax);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {   // 32 tokens per MFMA k-step
+      const int trow = st * 32 + kq * 8 + tq;
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = wn * 32 + i * 16 + tp * 4;
+        const bf16x4 lo = tr16(by + trow * 128 + col * 2), hi = tr16(by + (trow + 4) * 128 + col * 2);
+        a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wk * 32 + j * 16 + tp * 4;
+        const bf16x4 lo = tr16(bx + trow * 128 + col * 2), hi = tr16(bx + (trow + 4) * 128 + col * 2);
+        b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // C layout: col = lane&15 -> B column = k index; row = 4*kq + reg -> A row = n index
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = k0 + wk * 32 + j * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int nn = n0 + wn * 32 + i * 16 + kq * 4 + e;
+        if (nn < N && kk < K) atomicAdd(dw + (size_t)nn * lddw + kk, acc[i][j][e]);
+      }
+    }
+}
+
+// naive fp32 variant (gradient checks): thread per output element, block 16 x 16, token range per blockIdx.z
+__global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                   float* __restrict__ dw, int lddw, int L, int N, int K, int tokens_per_block) {
+  __shared__ float sy[32][17], sx[32][17];
+  const int tn = threadIdx.x & 15, tk = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + tn, k = blockIdx.y * 16 + tk;
+  const int t_begin = blockIdx.z * tokens_per_block, t_end = min(L, t_begin + tokens_per_block);
+  float acc = 0.f;
+  for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      const int r = i >> 4, c = i & 15, t = t0 + r;
+      sy[r][c] = (t < t_end && blockIdx.x * 16 + c < N) ? dy[(size_t)t * lddy + blockIdx.x * 16 + c] : 0.f;
+      sx[r][c] = (t < t_end && blockIdx.y * 16 + c < K) ? x[(size_t)t * ldx + blockIdx.y * 16 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) acc = fmaf(sy[r][tn], sx[r][tk], acc);
+  }
+  if (n < N && k < K) atomicAdd(dw + (size_t)n * lddw + k, acc);
+}
+
+int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, hipStream_t s) {
+  if (L == 0 || N == 0 || K == 0) return TTV_OK;
+  if (dt == TTV_BF16 && N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0) {
+    const int nb = ttv_cdiv(N, 64) * ttv_cdiv(K, 64);
+    int splits = ttv_cdiv(2048, nb);   // aim at >= 2048 blocks
+    if (splits > ttv_cdiv(L, 64)) splits = ttv_cdiv(L, 64);
+    if (splits < 1) splits = 1;
+    const int tpb = ttv_cdiv(ttv_cdiv(L, splits), 64) * 64;
+    dim3 grid(ttv_cdiv(N, 64), ttv_cdiv(K, 64), ttv_cdiv(L, tpb));
+    hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K, tpb);
+  } else if (dt == TTV_F32) {
+    const int tpb = 1024;
+    dim3 grid(ttv_cdiv(N, 16), ttv_cdiv(K, 16), ttv_cdiv(L, tpb));
+    hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(256), 0, s, (const float*)dy, lddy, (const float*)x, ldx, dw, lddw, L, N, K, tpb);
+  } else {
+    ttv_set_error("wgrad: bf16 needs N, K and leading dims multiples of 8");
+    return TTV_ERR_INVALID;
+  }
+  TTV_CHECK_LAUNCH("wgrad");
+  return TTV_OK;
+}
+
+// small-N / small-K linear backward helpers for the d <-> token_size projections (encoder proj_out [C,d], decoder proj_in [d,C])
+// dW[c, f] += sum_r a[r, c] * b[r, f]  (a: [rows, C] fp32 or T with C <= 8;  b: [rows, d]) ; one wave per row chunk
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void k_outer_small(const TA* __restrict__ a, int lda, int C, const TB* __restrict__ b, int ldb,
+                                                     const int* __restrict__ b_rows, float* __restrict__ dw, int lddw, int transpose_out,
+                                                     int rows, int d, int rows_per_block) {
+  // thread -> feature f (d <= 1024: loop), accumulates C partial sums over the block's rows
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int f = threadIdx.x; f < d; f += 256) {
+    float acc[TTV_MAX_FSQ];
+#pragma unroll
+    for (int c = 0; c < TTV_MAX_FSQ; ++c) acc[c] = 0.f;
+    for (int r = r0; r < r0 + rows_per_block && r < rows; ++r) {
+      const float bv = Cvt<TB>::to_f(b[(size_t)(b_rows ? b_rows[r] : r) * ldb + f]);
+#pragma unroll
+      for (int c = 0; c < TTV_MAX_FSQ; ++c)
+        if (c < C) acc[c] += Cvt<TA>::to_f(a[(size_t)r * lda + c]) * bv;
+    }
+#pragma unroll
+    for (int c = 0; c < TTV_MAX_FSQ; ++c)
+      if (c < C) atomicAdd(transpose_out ? dw + (size_t)f * lddw + c : dw + (size_t)c * lddw + f, acc[c]);
+  }
+}
+
+int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int b_dt, int ldb, const int* b_rows, float* dw, int lddw,
+                     int transpose_out, int rows, int d, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(C <= TTV_MAX_FSQ, "outer_small: C");
+  const int rpb = 64;
+  dim3 grid(ttv_cdiv(rows, rpb));
+#define OS(TA, TB) hipLaunchKernelGGL((k_outer_small<TA, TB>), grid, dim3(256), 0, s, (const TA*)a, lda, C, (const TB*)b, ldb, b_rows, dw, lddw, transpose_out, rows, d, rpb)
+  if (a_dt == TTV_F32 && b_dt == TTV_F32) OS(float, float);
+  else if (a_dt == TTV_F32 && b_dt == TTV_BF16) OS(float, bf16_t);
+  else if (a_dt == TTV_BF16 && b_dt == TTV_F32) OS(bf16_t, float);
+  else OS(bf16_t, bf16_t);
+#undef OS
+  TTV_CHECK_LAUNCH("outer_small");
+  return TTV_OK;
+}
+
+// out[r, f] = sum_c a[r, c] * w[c, f] (w_cf = 1) or w[f, c] (w_cf = 0): the d-side gradient of a d <-> C projection
+template <typename TA, typename TW, typename TO>
+__global__ __launch_bounds__(256) void k_expand_small(const TA* __restrict__ a, int lda, int C, const TW* __restrict__ w, int ldw, int w_cf,
+                                                      TO* __restrict__ out, int ldo, int rows, int d) {
+  const long total = (long)rows * d;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / d), f = (int)(i % d);
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += Cvt<TA>::to_f(a[(size_t)r * lda + c]) * Cvt<TW>::to_f(w_cf ? w[(size_t)c * ldw + f] : w[(size_t)f * ldw + c]);
+    out[(size_t)r * ldo + f] = Cvt<TO>::from_f(acc);
+  }
+}
+// out[r, c] = sum_f a[r, f] * w[f, c]   (d -> C contraction, e.g. dcodes = dh W_in)
+template <typename TA, typename TW>
+__global__ __launch_bounds__(256) void k_reduce_small(const TA* __restrict__ a, int lda, const int* __restrict__ a_rows, const TW* __restrict__ w,
+                                                      int ldw, int C, float* __restrict__ out, int ldo, int rows, int d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const TA* pa = a + (size_t)(a_rows ? a_rows[r] : r) * lda;
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int f = lane; f < d; f += 64) acc += Cvt<TA>::to_f(pa[f]) * Cvt<TW>::to_f(w[(size_t)f * ldw + c]);
+    acc = wave_sum(acc);
+    if (lane == 0) out[(size_t)r * ldo + c] = acc;
+  }
+}
+
+int ttvk_expand_small(const void* a, int a_dt, int lda, int C, const void* w, int w_dt, int ldw, int w_cf, void* out, int o_dt, int ldo,
+                      int rows, int d, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  const int nb = ew_blocks((long)rows * d);
+#define ES(TA, TW, TO) hipLaunchKernelGGL((k_expand_small<TA, TW, TO>), dim3(nb), dim3(256), 0, s, (const TA*)a, lda, C, (const TW*)w, ldw, w_cf, (TO*)out, ldo, rows, d)
+  if (a_dt == TTV_F32 && w_dt == TTV_BF16 && o_dt == TTV_BF16) ES(float, bf16_t, bf16_t);
+  else if (a_dt == TTV_F32 && w_dt == TTV_F32 && o_dt == TTV_F32) ES(float, float, float);
+  else if (a_dt == TTV_F32 && w_dt == TTV_BF16 && o_dt == TTV_F32) ES(float, bf16_t, float);
+  else { ttv_set_error("expand_small: dtype combination"); return TTV_ERR_INVALID; }
+#undef ES
+  TTV_CHECK_LAUNCH("expand_small");
+  return TTV_OK;
+}
+int ttvk_reduce_small(const void* a, int a_dt, int lda, const int* a_rows, const void* w, int w_dt, int ldw, int C, float* out, int ldo,
+                      int rows, int d, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  dim3 grid(ttv_cdiv(rows, 4));
+#define RS(TA, TW) hipLaunchKernelGGL((k_reduce_small<TA, TW>), grid, dim3(256), 0, s, (const TA*)a, lda, a_rows, (const TW*)w, ldw, C, out, ldo, rows, d)
+  if (a_dt == TTV_BF16 && w_dt == TTV_BF16) RS(bf16_t, bf16_t);
+  else if (a_dt == TTV_F32 && w_dt == TTV_F32) RS(float, float);
+  else if (a_dt == TTV_F32 && w_dt == TTV_BF16) RS(float, bf16_t);
+  else { ttv_set_error("reduce_small: dtype combination"); return TTV_ERR_INVALID; }
+#undef RS
+  TTV_CHECK_LAUNCH("reduce_small");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// delta[t, h] = sum_d dO[t, h, d] * O[t, h, d]
+template <typename T>
+__global__ __launch_bounds__(256) void k_attn_delta(const T* __restrict__ dout, int ldd, const T* __restrict__ o, int ldo,
+                                                    float* __restrict__ delta, int rows, int heads) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * heads) return;
+  const int t = i / heads, h = i % heads;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < 64; c += 4) {
+    const f32x4 a = Vec4<T>::load(dout + (size_t)t * ldd + h * 64 + c), b = Vec4<T>::load(o + (size_t)t * ldo + h * 64 + c);
+    acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  }
+  delta[i] = acc;
+}
+
+// naive fp32 backward: one wave per (query row, q-head); lane = head dim.  dk/dv accumulate with fp32 atomics into
+// [L, g] scratch (zeroed by the caller), dq is written directly.
+__global__ __launch_bounds__(256) void k_attn_bwd_f32(const float* __restrict__ qkvg, int ld, const float* __restrict__ dout, int ldd,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                      const int* __restrict__ cu, const int* __restrict__ row_seq,
+                                                      float* __restrict__ dqkvg, int ldg, float* __restrict__ dkv, int total_rows,
+                                                      int hq, int hkv, float scale) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= total_rows * hq) return;
+  const int t = idx / hq, h = idx % hq;
+  const int d_model = hq * 64, gqa = hkv * 64, kvh = h / (hq / hkv);
+  const int seq = row_seq[t];
+  const int s0 = cu[seq], s1 = cu[seq + 1];
+  const float q = qkvg[(size_t)t * ld + h * 64 + lane];
+  const float dov = dout[(size_t)t * ldd + h * 64 + lane];
+  const float l = lse[(size_t)t * hq + h], dl = delta[(size_t)t * hq + h];
+  float dq = 0.f;
+  for (int j = s0; j < s1; ++j) {
+    const float kv = qkvg[(size_t)j * ld + 2 * d_model + kvh * 64 + lane];
+    const float vv = qkvg[(size_t)j * ld + 2 * d_model + gqa + kvh * 64 + lane];
+    const float sdot = wave_sum(q * kv) * scale;
+    const float p = expf(sdot - l);
+    const float dp = wave_sum(dov * vv);
+    const float ds = p * (dp - dl) * scale;
+    dq += ds * kv;
+    atomicAdd(dkv + (size_t)j * 2 * gqa + kvh * 64 + lane, ds * q);
+    atomicAdd(dkv + (size_t)j * 2 * gqa + gqa + kvh * 64 + lane, p * dov);
+  }
+  dqkvg[(size_t)t * ldg + h * 64 + lane] = dq;
+}
+
+// ---- bf16 MFMA kernels.  LDS tiles are row-major [64 rows][64 cols] bf16 with 128-byte rows. ----
+__device__ __forceinline__ void stage_tile64(uint4* dst, const bf16_t* src, int ld, int row0, int row_end, int tid) {
+  // 64 rows x 8 chunks, 2 chunks per thread; rows past row_end are zero-filled
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 3) + 32 * i, c = tid & 7;
+    dst[r * 8 + c] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
+  }
+}
+// fragment with 8 consecutive COLUMNS of one row (K-contiguous operand): rows r0+l15, columns kc*8.. (b128)
+__device__ __forceinline__ bf16x8 frag_row(const uint4* tile, int row, int chunk) { return __builtin_bit_cast(bf16x8, tile[row * 8 + chunk]); }
+// fragment with 8 consecutive ROWS (row0 + 8*kq + 0..7) of one column col0 + l15: two transposed reads
+__device__ __forceinline__ bf16x8 frag_col(const uint4* tile, int row0, int col0, int lane) {
+  const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, kq = lane >> 4;
+  const char* b = reinterpret_cast<const char*>(tile) + (row0 + kq * 8 + tq) * 128 + (col0 + tp * 4) * 2;
+  const bf16x4 lo = tr16(b), hi = tr16(b + 4 * 128);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// S^T and dP^T for a 64-key x 64-query block pair, wave (wa, wb) owns keys wa*32.. x queries wb*32.. :
+//   st[i][j]  = sum_d K[key][d] Q[q][d]      (A = K rows, B = Q rows)  -> lane: 4 consecutive KEYS (rows) for query col l15
+// Returns P^T and dS^T (scaled) in the same layout.
+struct PdS { f32x4 p[2][2], ds[2][2]; };
+__device__ __forceinline__ PdS attn_recompute(const uint4* kt, const uint4* vt, const uint4* qt, const uint4* dot_, int wa, int wb,
+                                              int lane, const float* lse_q, const float* delta_q, int key0, int q0, int S, float scale) {
+  const int l15 = lane & 15, kq = lane >> 4;
+  PdS r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { r.p[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; r.ds[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 ak[2], av[2], bq[2], bd[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ak[i] = frag_row(kt, wa * 32 + i * 16 + l15, ks * 4 + kq);
+      av[i] = frag_row(vt, wa * 32 + i * 16 + l15, ks * 4 + kq);
+      bq[i] = frag_row(qt, wb * 32 + i * 16 + l15, ks * 4 + kq);
+      bd[i] = frag_row(dot_, wb * 32 + i * 16 + l15, ks * 4 + kq);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        r.p[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[i], bq[j], r.p[i][j], 0, 0, 0);    // S^T
+        r.ds[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bd[j], r.ds[i][j], 0, 0, 0);  // dP^T
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qi = wb * 32 + j * 16 + l15;     // query of this lane's column
+    const float l = lse_q[qi], dl = delta_q[qi];
+    const bool qv = q0 + qi < S;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = key0 + wa * 32 + i * 16 + kq * 4 + e;
+        const float p = (qv && key < S) ? __expf(r.p[i][j][e] * scale - l) : 0.f;
+        r.ds[i][j][e] = p * (r.ds[i][j][e] - dl) * scale;
+        r.p[i][j][e] = p;
+      }
+  }
+  return r;
+}
+
+// dK, dV of one 64-key block of one (sequence, kv-head): loops over the group's q-heads and all 64-query blocks.
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                      const int* __restrict__ cu, const int* __restrict__ blocks, bf16_t* __restrict__ dqkvg,
+                                                      int ldg, int hq, int hkv, float scale) {
+  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], pt[512], st[512];
+  __shared__ float lse_s[64], delta_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave & 1, wb = wave >> 1;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int seq = blocks[2 * blockIdx.x], key0 = blocks[2 * blockIdx.x + 1];
+  const int kvh = blockIdx.y;
+  const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int d_model = hq * 64, gqa = hkv * 64, rep = hq / hkv;
+  const bf16_t* base = qkvg + (size_t)s0 * ld;
+  stage_tile64(kt, base + 2 * d_model + kvh * 64, ld, key0, S, tid);
+  stage_tile64(vt, base + 2 * d_model + gqa + kvh * 64, ld, key0, S, tid);
+  // accumulators: dK^T / dV^T tiles with rows = d (A operand = transposed Q / dO), cols = key: wave owns d (wa*32..) x key (wb*32..)
+  f32x4 dk[2][2], dv[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int hr = 0; hr < rep; ++hr) {
+    const int h = kvh * rep + hr;
+    for (int q0 = 0; q0 < S; q0 += 64) {
+      __syncthreads();
+      stage_tile64(qt, base + h * 64, ld, q0, S, tid);
+      stage_tile64(dt_, dout + (size_t)s0 * ldd + h * 64, ldd, q0, S, tid);
+      if (tid < 64) {
+        const int q = q0 + tid;
+        lse_s[tid] = q < S ? lse[(size_t)(s0 + q) * hq + h] : 0.f;
+        delta_s[tid] = q < S ? delta[(size_t)(s0 + q) * hq + h] : 0.f;
+      }
+      __syncthreads();
+      const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
+      // P^T / dS^T -> LDS as [query][key] (lane holds 4 consecutive keys of one query: one 8-byte store each)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int qi = wb * 32 + j * 16 + l15, kc = wa * 32 + i * 16 + kq * 4;
+          const bf16x4 pb = {(bf16_t)r.p[i][j][0], (bf16_t)r.p[i][j][1], (bf16_t)r.p[i][j][2], (bf16_t)r.p[i][j][3]};
+          const bf16x4 sb = {(bf16_t)r.ds[i][j][0], (bf16_t)r.ds[i][j][1], (bf16_t)r.ds[i][j][2], (bf16_t)r.ds[i][j][3]};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(pt) + qi * 128 + kc * 2) = pb;
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(st) + qi * 128 + kc * 2) = sb;
+        }
+      __syncthreads();
+      // dV^T[d][key] += sum_q dO^T[d][q] P[q][key] ; dK^T[d][key] += sum_q Q^T[d][q] dS[q][key]   (contraction over queries)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        bf16x8 ado[2], aq[2], bp[2], bs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ado[i] = frag_col(dt_, qs * 32, wa * 32 + i * 16, lane);   // rows = d, k = queries
+          aq[i] = frag_col(qt, qs * 32, wa * 32 + i * 16, lane);
+          bp[i] = frag_col(pt, qs * 32, wb * 32 + i * 16, lane);     // cols = key, k = queries
+          bs[i] = frag_col(st, qs * 32, wb * 32 + i * 16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            dv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[i], bp[j], dv[i][j], 0, 0, 0);
+            dk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bs[j], dk[i][j], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // lane: 4 consecutive d (rows) of key (col) l15
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = key0 + wb * 32 + j * 16 + l15, d0 = wa * 32 + i * 16 + kq * 4;
+      if (key < S) {
+        bf16_t* row = dqkvg + (size_t)(s0 + key) * ldg + 2 * d_model + kvh * 64 + d0;
+        Vec4<bf16_t>::store(row, dk[i][j]);
+        Vec4<bf16_t>::store(row + gqa, dv[i][j]);
+      }
+    }
+}
+
+// dQ of one 64-query block of one (sequence, q-head): loops over all 64-key blocks.
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                     const float* __restrict__ lse, const float* __restrict__ delta,
+                                                     const int* __restrict__ cu, const int* __restrict__ blocks, bf16_t* __restrict__ dqkvg,
+                                                     int ldg, int hq, int hkv, float scale) {
+  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], st[512];
+  __shared__ float lse_s[64], delta_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave & 1, wb = wave >> 1;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int seq = blocks[2 * blockIdx.x], q0 = blocks[2 * blockIdx.x + 1];
+  const int h = blockIdx.y;
+  const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int d_model = hq * 64, gqa = hkv * 64, kvh = h / (hq / hkv);
+  const bf16_t* base = qkvg + (size_t)s0 * ld;
+  stage_tile64(qt, base + h * 64, ld, q0, S, tid);
+  stage_tile64(dt_, dout + (size_t)s0 * ldd + h * 64, ldd, q0, S, tid);
+  if (tid < 64) {
+    const int q = q0 + tid;
+    lse_s[tid] = q < S ? lse[(size_t)(s0 + q) * hq + h] : 0.f;
+    delta_s[tid] = q < S ? delta[(size_t)(s0 + q) * hq + h] : 0.f;
+  }
+  // dQ^T[d][q]: wave owns d (wa*32..) x q (wb*32..)
+  f32x4 dq[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dq[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int key0 = 0; key0 < S; key0 += 64) {
+    __syncthreads();
+    stage_tile64(kt, base + 2 * d_model + kvh * 64, ld, key0, S, tid);
+    stage_tile64(vt, base + 2 * d_model + gqa + kvh * 64, ld, key0, S, tid);
+    __syncthreads();
+    const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int qi = wb * 32 + j * 16 + l15, kc = wa * 32 + i * 16 + kq * 4;
+        const bf16x4 sb = {(bf16_t)r.ds[i][j][0], (bf16_t)r.ds[i][j][1], (bf16_t)r.ds[i][j][2], (bf16_t)r.ds[i][j][3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(st) + qi * 128 + kc * 2) = sb;
+      }
+    __syncthreads();
+    // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]: A rows = d (K tile transposed), B cols = q with k = keys (row read of dS[q][key])
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = frag_col(kt, ks * 32, wa * 32 + i * 16, lane);
+        b[i] = frag_row(st, wb * 32 + i * 16 + l15, ks * 4 + kq);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dq[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], dq[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = q0 + wb * 32 + j * 16 + l15, d0 = wa * 32 + i * 16 + kq * 4;
+      if (q < S) Vec4<bf16_t>::store(dqkvg + (size_t)(s0 + q) * ldg + h * 64 + d0, dq[i][j]);
+    }
+}
+
+// blocks64: device int32 [n,2] = (sequence, first row) for 64-row blocks; row_seq: device int32 [L] sequence of every row
+// (fp32 path); dkv_scratch: fp32 [L, 2g] zeroed by this function (fp32 path only).
+int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
+                       const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
+                       int total_rows, int hq, int hkv, int dt, hipStream_t s) {
+  if (total_rows == 0) return TTV_OK;
+  const float scale = 0.125f;
+  const int d_model = hq * 64, gqa = hkv * 64;
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_attn_delta<bf16_t>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const bf16_t*)dout, ldd, (const bf16_t*)o, ldo, delta, total_rows, hq);
+  else hipLaunchKernelGGL((k_attn_delta<float>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const float*)dout, ldd, (const float*)o, ldo, delta, total_rows, hq);
+  TTV_CHECK_LAUNCH("attn_delta");
+  if (dt == TTV_BF16) {
+    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(n_blocks64, hkv), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale);
+    TTV_CHECK_LAUNCH("attn_bwd_dkv");
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(n_blocks64, hq), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale);
+    TTV_CHECK_LAUNCH("attn_bwd_dq");
+  } else {
+    TTV_CHECK_ARG(dkv_scratch && row_seq, "attention_bwd: fp32 path needs scratch and row map");
+    (void)hipMemsetAsync(dkv_scratch, 0, (size_t)total_rows * 2 * gqa * sizeof(float), s);
+    hipLaunchKernelGGL(k_attn_bwd_f32, dim3(ttv_cdiv(total_rows * hq, 4)), dim3(256), 0, s, (const float*)qkvg, ld, (const float*)dout, ldd, lse, delta, cu, row_seq, (float*)dqkvg, ldg, dkv_scratch, total_rows, hq, hkv, scale);
+    TTV_CHECK_LAUNCH("attn_bwd_f32");
+    // copy dk|dv scratch [L, 2g] into the k, v columns of dqkvg
+    (void)hipMemcpy2DAsync((float*)dqkvg + 2 * d_model, (size_t)ldg * sizeof(float), dkv_scratch, (size_t)2 * gqa * sizeof(float),
+                           (size_t)2 * gqa * sizeof(float), total_rows, hipMemcpyDeviceToDevice, s);
+  }
+  return TTV_OK;
+}

@@ -109,7 +109,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, int C, const T* __restrict__ w /*[d,C]*/,
                                                    const T* __restrict__ bias, const float* __restrict__ mask_token,
                                                    const float* __restrict__ gain, T* __restrict__ x, int ld,
-                                                   const int* __restrict__ rows_map, int rows, int d, float eps) {
+                                                   const int* __restrict__ rows_map, int rows, int d, float eps, T* __restrict__ hpre) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
   if (r >= rows) return;
@@ -133,6 +133,8 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, 
       v[it][e] = h;
       ss += h * h;
     }
+    if (hpre && (it * 64 + lane) * 4 < d)   // training tape: the pre-norm row proj_in(codes) + bias + mask_token
+      Vec4<T>::store(hpre + (size_t)r * d + (it * 64 + lane) * 4, (f32x4){v[it][0], v[it][1], v[it][2], v[it][3]});
   }
   ss = wave_sum(ss);
   const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
@@ -150,14 +152,19 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, 
 
 int ttvk_dec_embed(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain,
                    void* x, int dtype, int ld, const int* rows_map, int rows, int d, float eps, hipStream_t s) {
+  return ttvk_dec_embed_ex(codes, C, w, bias, mask_token, gain, x, dtype, ld, rows_map, rows, d, eps, nullptr, s);
+}
+
+int ttvk_dec_embed_ex(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain, void* x,
+                      int dtype, int ld, const int* rows_map, int rows, int d, float eps, void* hpre, hipStream_t s) {
   if (rows == 0) return TTV_OK;
   TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_FSQ, "dec_embed: token_size %d out of range", C);
   TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "dec_embed: width");
   dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
   if (dtype == TTV_BF16)
-    hipLaunchKernelGGL((k_dec_embed<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)codes, C, (const bf16_t*)w, (const bf16_t*)bias, mask_token, gain, (bf16_t*)x, ld, rows_map, rows, d, eps);
+    hipLaunchKernelGGL((k_dec_embed<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)codes, C, (const bf16_t*)w, (const bf16_t*)bias, mask_token, gain, (bf16_t*)x, ld, rows_map, rows, d, eps, (bf16_t*)hpre);
   else
-    hipLaunchKernelGGL((k_dec_embed<float>), grid, dim3(256), 0, s, (const float*)codes, C, (const float*)w, (const float*)bias, mask_token, gain, (float*)x, ld, rows_map, rows, d, eps);
+    hipLaunchKernelGGL((k_dec_embed<float>), grid, dim3(256), 0, s, (const float*)codes, C, (const float*)w, (const float*)bias, mask_token, gain, (float*)x, ld, rows_map, rows, d, eps, (float*)hpre);
   TTV_CHECK_LAUNCH("dec_embed");
   return TTV_OK;
 }
@@ -394,7 +401,7 @@ int ttvk_patch_copy(bool scatter, void* const* clips, const int* clip_desc, int 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_rope_apply(T* __restrict__ x, int ld, int rows, int heads,
-                                                    const float* __restrict__ cs) {
+                                                    const float* __restrict__ cs, float sgn) {
   // thread -> (row, head, 4 consecutive dims = 2 complex pairs)
   const long total = (long)rows * heads * 16;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -403,19 +410,24 @@ __global__ __launch_bounds__(256) void k_rope_apply(T* __restrict__ x, int ld, i
     T* p = x + r * ld + h * 64 + q4 * 4;
     const float* c = cs + r * 64 + q4 * 2;
     f32x4 v = Vec4<T>::load(p);
-    const float c0 = c[0], c1 = c[1], s0 = c[32], s1 = c[33];
+    const float c0 = c[0], c1 = c[1], s0 = sgn * c[32], s1 = sgn * c[33];   // sgn = -1: inverse rotation (backward)
     f32x4 o = {v[0] * c0 - v[1] * s0, v[0] * s0 + v[1] * c0, v[2] * c1 - v[3] * s1, v[2] * s1 + v[3] * c1};
     Vec4<T>::store(p, o);
   }
 }
 
 int ttvk_rope_apply(void* x, int dtype, int ld, int rows, int heads, const float* cs, hipStream_t s) {
+  return ttvk_rope_apply_dir(x, dtype, ld, rows, heads, cs, 0, s);
+}
+
+int ttvk_rope_apply_dir(void* x, int dtype, int ld, int rows, int heads, const float* cs, int conj, hipStream_t s) {
   if (rows == 0) return TTV_OK;
+  const float sgn = conj ? -1.f : 1.f;
   const long total = (long)rows * heads * 16;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_rope_apply<bf16_t>), dim3(blocks), dim3(256), 0, s, (bf16_t*)x, ld, rows, heads, cs);
-  else hipLaunchKernelGGL((k_rope_apply<float>), dim3(blocks), dim3(256), 0, s, (float*)x, ld, rows, heads, cs);
+  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_rope_apply<bf16_t>), dim3(blocks), dim3(256), 0, s, (bf16_t*)x, ld, rows, heads, cs, sgn);
+  else hipLaunchKernelGGL((k_rope_apply<float>), dim3(blocks), dim3(256), 0, s, (float*)x, ld, rows, heads, cs, sgn);
   TTV_CHECK_LAUNCH("rope_apply");
   return TTV_OK;
 }
@@ -437,5 +449,35 @@ int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_histogram, dim3(blocks), dim3(256), 0, s, idx, n, (unsigned long long*)counts, size);
   TTV_CHECK_LAUNCH("histogram");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the constant rows v[f] = m * rsqrt(m^2+eps) * gain[f] (k_fill_const_rows), given colsum[f] = sum over those
+// rows of the incoming gradient:  dgain[f] += colsum[f] * m*rstd ;  dmask += sum_f colsum[f]*gain[f] * eps*(m^2+eps)^-1.5
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_const_rows_bwd(const float* __restrict__ colsum, const float* __restrict__ mask_token,
+                                                        const float* __restrict__ gain, float eps, float* __restrict__ dgain,
+                                                        float* __restrict__ dmask, int d) {
+  __shared__ float red[4];
+  const float m = round_to<T>(mask_token[0]);
+  const float rstd = 1.0f / sqrtf(m * m + eps);
+  float acc = 0.f;
+  for (int f = threadIdx.x; f < d; f += 256) {
+    atomicAdd(dgain + f, colsum[f] * m * rstd);
+    acc += colsum[f] * gain[f];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dmask, (red[0] + red[1] + red[2] + red[3]) * eps * rstd * rstd * rstd);
+}
+
+int ttvk_const_rows_bwd(const float* colsum, const float* mask_token, const float* gain, int dt, float eps, float* dgain, float* dmask,
+                        int d, hipStream_t s) {
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_const_rows_bwd<bf16_t>), dim3(1), dim3(256), 0, s, colsum, mask_token, gain, eps, dgain, dmask, d);
+  else hipLaunchKernelGGL((k_const_rows_bwd<float>), dim3(1), dim3(256), 0, s, colsum, mask_token, gain, eps, dgain, dmask, d);
+  TTV_CHECK_LAUNCH("const_rows_bwd");
   return TTV_OK;
 }

@@ -57,9 +57,39 @@ bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 
 // ---- ttv_attn.hip ----
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
-                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s);
+                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s, float* lse_out = nullptr);
 
 // ---- ttv_mlp.hip ----
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner);
 int ttvk_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
                    const float* post_gain, float alpha, float eps, int M, hipStream_t s);
+
+// ---- ttv_bwd.hip (backward kernels) ----
+int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void* dy, int dy_dt, int lddy, const int* dyr,
+                     const float* gain, void* dx, int dx_dt, int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps,
+                     hipStream_t s);
+int ttvk_colsum(const void* a, int dt, int lda, const int* rows_map, int rows, int n, float* out, hipStream_t s);
+int ttvk_sumall(const void* a, int dt, int lda, const int* rows_map, int rows, int n, const float* colw, float scale, float* out, hipStream_t s);
+int ttvk_gate_fwd(const void* a, int lda, const void* gate, int ldg, void* ag, int ldo, int rows, int d, int dt, hipStream_t s);
+int ttvk_gate_bwd(const void* dag, int ldd, const void* a, int lda, const void* gate, int ldg, void* da, int ldda, void* dgate, int lddg,
+                  int rows, int d, int dt, hipStream_t s);
+int ttvk_geglu_fwd(const void* u, int ldu, void* h, int ldh, int rows, int I, int dt, hipStream_t s);
+int ttvk_geglu_bwd(const void* u, int ldu, const void* dh, int lddh, void* du, int lddu, int rows, int I, int dt, hipStream_t s);
+int ttvk_scale_cast(const float* a, float alpha, float* b, void* c, int dt, long n, hipStream_t s);
+int ttvk_to_f32(const void* a, int dt, float* b, long n, int accumulate, hipStream_t s);
+int ttvk_fsq_bwd(const ttv_fsq_params* fp, const float* z, const void* dcodes, int dt, float* dz, int rows, hipStream_t s);
+int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, hipStream_t s);
+int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int b_dt, int ldb, const int* b_rows, float* dw, int lddw,
+                     int transpose_out, int rows, int d, hipStream_t s);
+int ttvk_expand_small(const void* a, int a_dt, int lda, int C, const void* w, int w_dt, int ldw, int w_cf, void* out, int o_dt, int ldo,
+                      int rows, int d, hipStream_t s);
+int ttvk_reduce_small(const void* a, int a_dt, int lda, const int* a_rows, const void* w, int w_dt, int ldw, int C, float* out, int ldo,
+                      int rows, int d, hipStream_t s);
+int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
+                       const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
+                       int total_rows, int hq, int hkv, int dt, hipStream_t s);
+int ttvk_rope_apply_dir(void* x, int dtype, int ld, int rows, int heads, const float* cs, int conj, hipStream_t s);
+int ttvk_dec_embed_ex(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain, void* x,
+                      int dtype, int ld, const int* rows_map, int rows, int d, float eps, void* hpre, hipStream_t s);
+int ttvk_const_rows_bwd(const float* colsum, const float* mask_token, const float* gain, int dt, float eps, float* dgain, float* dmask,
+                        int d, hipStream_t s);

@@ -1,0 +1,362 @@
+// Training step of a tower (reference train.py:65-83 = autograd through blocks.py / transformer.py / fsq.py):
+// a tape-recording forward (unfused kernel sequence, every tensor backward needs is written into the caller's tape)
+// and the hand-written backward launch sequence.  Gradients of parameters are ACCUMULATED into caller-zeroed fp32
+// buffers (atomics in the reduction kernels); activation gradients travel in the compute dtype, the residual-stream
+// gradient in fp32.
+#include <stdio.h>
+
+#include "ttv_common.h"
+#include "ttv_kernels.h"
+
+#define TTV_TRY(expr)                \
+  do {                               \
+    int rc__ = (expr);               \
+    if (rc__ != TTV_OK) return rc__; \
+  } while (0)
+
+static inline int64_t al(int64_t v) { return (v + 255) & ~(int64_t)255; }
+static inline int esz(int dt) { return dt == TTV_BF16 ? 2 : 4; }
+
+struct Tape {
+  char* base;
+  int64_t total;
+  // per tower
+  char *patches, *pe, *hpre, *pn;     // encoder: gathered patches, proj_in output (pre-norm); decoder: pre-norm latent rows, ln_post out
+  char* X[65];                        // residual stream at every layer boundary (X[0] = tower input rows, X[layers] = output)
+  struct L { char *xn1, *qkvg, *a, *ag, *x1, *xn2, *u, *h; float *lse, *y1, *y2; } l[64];
+};
+
+static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
+  Tape t;
+  const int64_t e = esz(d->dtype), L = b->total_rows, P = b->sum_patches, K = b->sum_tokens, dm = d->width;
+  const int64_t g = (int64_t)d->kv_heads * d->head_dim, nq = 2 * dm + 2 * g;
+  const int64_t pd = (int64_t)d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
+  t.base = base;
+  t.patches = t.pe = t.hpre = t.pn = nullptr;
+  if (d->kind == TTV_ENCODER) { t.patches = take(P * pd * e); t.pe = take(P * dm * e); }
+  else { t.hpre = take(K * dm * e); t.pn = take(P * dm * e); }
+  for (int i = 0; i <= d->layers; ++i) t.X[i] = take(L * dm * e);
+  for (int i = 0; i < d->layers; ++i) {
+    Tape::L& l = t.l[i];
+    l.xn1 = take(L * dm * e); l.qkvg = take(L * nq * e); l.lse = (float*)take(L * d->q_heads * 4);
+    l.a = take(L * dm * e); l.ag = take(L * dm * e);
+    l.y1 = (float*)take(i > 0 ? L * dm * 4 : 0); l.x1 = take(L * dm * e); l.xn2 = take(L * dm * e);
+    l.u = take(L * 2 * d->inner * e); l.h = take(L * d->inner * e); l.y2 = (float*)take(i > 0 ? L * dm * 4 : 0);
+  }
+  t.total = off;
+  return t;
+}
+
+struct BwdWs {
+  float *dxa, *dxb, *delta, *dkv, *colsum, *small_f32;
+  char *g_d, *g_d2, *g_i, *g_2i, *g_nq, *g_pd;
+  int64_t total;
+};
+static BwdWs carve_bwd(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
+  BwdWs w;
+  const int64_t e = esz(d->dtype), L = b->total_rows, P = b->sum_patches, dm = d->width;
+  const int64_t g = (int64_t)d->kv_heads * d->head_dim, nq = 2 * dm + 2 * g;
+  const int64_t pd = (int64_t)d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
+  w.dxa = (float*)take(L * dm * 4); w.dxb = (float*)take(L * dm * 4);
+  w.delta = (float*)take(L * d->q_heads * 4);
+  w.dkv = (float*)take(d->dtype == TTV_F32 ? L * 2 * g * 4 : 0);
+  w.colsum = (float*)take(dm * 4);
+  w.small_f32 = (float*)take(L * dm * 4);          // fp32 [rows, d] scratch for the d <-> token_size projections
+  w.g_d = take(L * dm * e); w.g_d2 = take(L * dm * e); w.g_i = take(L * d->inner * e); w.g_2i = take(L * 2 * d->inner * e);
+  w.g_nq = take(L * nq * e); w.g_pd = take(P * pd * e);
+  w.total = off;
+  return w;
+}
+
+static int check(const ttv_tower_dims* d, const ttv_batch* b) {
+  TTV_CHECK_ARG(d && b, "null dims/batch");
+  TTV_CHECK_ARG(d->dtype == TTV_BF16 || d->dtype == TTV_F32, "bad dtype");
+  TTV_CHECK_ARG(d->layers >= 1 && d->layers <= 64, "layers out of range");
+  TTV_CHECK_ARG(d->head_dim == 64 && d->width == d->q_heads * 64 && d->width <= 1024, "width must be q_heads*64 <= 1024");
+  TTV_CHECK_ARG(b->blocks64 && b->row_seq, "training needs batch.blocks64 and batch.row_seq");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward (tape)
+static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, Tape& t, hipStream_t s) {
+  const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
+  for (int i = 0; i < d->layers; ++i) {
+    const ttv_layer_weights& lw = w->layers[i];
+    Tape::L& l = t.l[i];
+    TTV_TRY(ttvk_rmsnorm(t.X[i], dt, dm, nullptr, l.xn1, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+    GemmArgs a = {};
+    a.dtype = dt; a.x = l.xn1; a.ldx = dm; a.w = lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = l.qkvg; a.ldy = nq;
+    a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+    TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
+    TTV_TRY(ttvk_attention(l.qkvg, nq, l.a, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim, 0, dt, s, l.lse));
+    TTV_TRY(ttvk_gate_fwd(l.a, dm, (const char*)l.qkvg + (size_t)dm * esz(dt), nq, l.ag, dm, L, dm, dt, s));
+    GemmArgs o = {};
+    o.dtype = dt; o.x = l.ag; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = t.X[i]; o.ldr = dm;
+    if (i == 0) {
+      o.alpha = 1.f; o.y = l.x1; o.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
+    } else {
+      o.alpha = d->alpha; o.y = l.y1; o.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
+      TTV_TRY(ttvk_rmsnorm(l.y1, TTV_F32, dm, nullptr, l.x1, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
+    }
+    TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+    GemmArgs f = {};
+    f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = 2 * I; f.K = dm; f.y = l.u; f.ldy = 2 * I;
+    TTV_TRY(ttvk_gemm(EPI_STORE, f, s));
+    TTV_TRY(ttvk_geglu_fwd(l.u, 2 * I, l.h, I, L, I, dt, s));
+    GemmArgs f3 = {};
+    f3.dtype = dt; f3.x = l.h; f3.ldx = I; f3.w = lw.w3; f3.ldw = I; f3.M = L; f3.N = dm; f3.K = I; f3.resid = l.x1; f3.ldr = dm;
+    if (i == 0) {
+      f3.alpha = 1.f; f3.y = t.X[i + 1]; f3.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
+    } else {
+      f3.alpha = d->alpha; f3.y = l.y2; f3.ldy = dm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
+      TTV_TRY(ttvk_rmsnorm(l.y2, TTV_F32, dm, nullptr, t.X[i + 1], dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s));
+    }
+  }
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ backward (layers)
+// On entry ws.dxa holds dL/dX[layers] (fp32); on exit ws.dxa holds dL/dX[0].
+static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* b, Tape& t,
+                           const ttv_tower_grads* gr, BwdWs& ws, hipStream_t s) {
+  const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
+  const long nLd = (long)L * dm;
+  float* dx = ws.dxa;     // gradient of the layer output
+  float* tmp = ws.dxb;
+  for (int i = d->layers - 1; i >= 0; --i) {
+    const ttv_layer_weights& lw = w->layers[i];
+    const ttv_layer_weights_t& lt = wt->layers[i];
+    const ttv_layer_grads& lg = gr->layers[i];
+    Tape::L& l = t.l[i];
+    // ---------------- feed-forward sub-layer: X[i+1] = post_ln(alpha*x1 + w3 h)  (layer 0: x1 + w3 h) ----------------
+    float* dx1;
+    if (i > 0) {
+      TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, L, dm, d->eps, s));
+      // tmp = dy2 ; df (T) = dy2 ; dx1 = alpha * dy2 (into dx)
+      TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLd, s));
+    } else {
+      TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, ws.g_d, dt, nLd, s));   // df = (T) dx ; dx1 = dx
+    }
+    dx1 = dx;
+    // dh = df W3 ; dW3 += df^T h
+    GemmArgs a = {};
+    a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = L; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
+    TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, L, dm, I, dt, s));
+    TTV_TRY(ttvk_geglu_bwd(l.u, 2 * I, ws.g_i, I, ws.g_2i, 2 * I, L, I, dt, s));
+    // dxn2 = du W12 ; dW12 += du^T xn2
+    GemmArgs c = {};
+    c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = L; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
+    TTV_TRY(ttvk_gemm(EPI_STORE, c, s));
+    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, s));
+    // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2)
+    TTV_TRY(ttvk_rmsnorm_bwd(l.x1, dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.ffd_norm, dx1, TTV_F32, dm, nullptr, 1, lg.ffd_norm, L, dm, d->eps, s));
+    // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
+    if (i > 0) {
+      TTV_TRY(ttvk_rmsnorm_bwd(l.y1, TTV_F32, dm, nullptr, dx1, TTV_F32, dm, nullptr, lw.attn_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.attn_post_ln, L, dm, d->eps, s));
+      TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLd, s));   // do = (T) dy1 ; dx = alpha * dy1
+    } else {
+      TTV_TRY(ttvk_scale_cast(dx1, 1.f, nullptr, ws.g_d, dt, nLd, s));
+    }
+    // dag = do Wo ; dWo += do^T ag
+    GemmArgs e = {};
+    e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = L; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
+    TTV_TRY(ttvk_gemm(EPI_STORE, e, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.ag, dm, lg.out_proj, dm, L, dm, dm, dt, s));
+    // da = dag*sigmoid(gate) (into g_d) ; dgate -> dqkvg[:, d:2d]
+    char* dqkvg = ws.g_nq;
+    const size_t es = esz(dt);
+    TTV_TRY(ttvk_gate_bwd(ws.g_d2, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt, s));
+    // attention backward -> dq, dk, dv columns of dqkvg
+    TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, ws.g_d, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
+                               ws.dkv, L, d->q_heads, d->kv_heads, dt, s));
+    // inverse rotation of dq and dk
+    TTV_TRY(ttvk_rope_apply_dir(dqkvg, dt, nq, L, d->q_heads, b->rope_cs, 1, s));
+    TTV_TRY(ttvk_rope_apply_dir(dqkvg + (size_t)2 * dm * es, dt, nq, L, d->kv_heads, b->rope_cs, 1, s));
+    // dxn1 = dqkvg Wqkv ; dWqkv += dqkvg^T xn1
+    GemmArgs q = {};
+    q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
+    TTV_TRY(ttvk_gemm(EPI_STORE, q, s));
+    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, s));
+    // dx += rmsnorm_bwd(X[i], pre_ln, dxn1)
+    TTV_TRY(ttvk_rmsnorm_bwd(t.X[i], dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.pre_ln, dx, TTV_F32, dm, nullptr, 1, lg.pre_ln, L, dm, d->eps, s));
+  }
+  return TTV_OK;
+}
+
+extern "C" {
+
+int64_t ttv_tower_tape_bytes(const ttv_tower_dims* dims, const ttv_batch* batch) {
+  if (!dims || !batch) return -1;
+  return carve_tape(dims, batch, nullptr).total;
+}
+int64_t ttv_tower_bwd_workspace_bytes(const ttv_tower_dims* dims, const ttv_batch* batch) {
+  if (!dims || !batch) return -1;
+  return carve_bwd(dims, batch, nullptr).total;
+}
+
+int ttv_fsq_backward(const ttv_fsq_params* p, const float* z, const void* dcodes, int dcodes_dtype, float* dz, int rows, void* stream) {
+  TTV_CHECK_ARG(p && (rows == 0 || (z && dcodes && dz)), "fsq_backward: null buffer");
+  return ttvk_fsq_bwd(p, z, dcodes, dcodes_dtype, dz, rows, (hipStream_t)stream);
+}
+
+int ttv_encoder_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const void* const* clips, float* z,
+                              void* tape, int64_t tape_bytes, void* stream) {
+  TTV_TRY(check(d, b));
+  TTV_CHECK_ARG(d->kind == TTV_ENCODER && w && w->layers && clips && z && tape, "encoder_forward_train: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Tape t = carve_tape(d, b, (char*)tape);
+  TTV_CHECK_ARG(t.total <= tape_bytes, "encoder_forward_train: tape too small");
+  const int dm = d->width, dt = d->dtype, P = b->sum_patches;
+  const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_patch_copy(false, (void* const*)(clips + c0), b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, t.patches, pd, dt, b->max_patches_per_clip, s));
+  }
+  GemmArgs a = {};
+  a.dtype = dt; a.x = t.patches; a.ldx = pd; a.w = w->proj_in_w; a.ldw = pd; a.M = P; a.N = dm; a.K = pd; a.y = t.pe; a.ldy = dm;
+  a.bias = w->proj_in_b; a.add_scalar = w->mask_token;
+  TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+  TTV_TRY(ttvk_rmsnorm(t.pe, dt, dm, nullptr, t.X[0], dt, dm, b->patch_rows, w->ln_pre_p, P, dm, d->eps, s));
+  TTV_TRY(ttvk_fill_const_rows(t.X[0], dt, dm, b->latent_rows, b->sum_tokens, dm, w->mask_token, w->ln_pre_t, d->eps, s));
+  TTV_TRY(layers_forward_train(d, w, b, t, s));
+  TTV_TRY(ttvk_enc_tail(t.X[d->layers], dt, dm, b->latent_rows, b->sum_tokens, dm, w->ln_post, d->eps, w->proj_out_w, w->proj_out_b, d->token_size, nullptr, z, nullptr, nullptr, nullptr, s));
+  return TTV_OK;
+}
+
+int ttv_encoder_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* b, const float* dz,
+                         void* tape, const ttv_tower_grads* gr, void* const* dclips, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTV_TRY(check(d, b));
+  TTV_CHECK_ARG(d->kind == TTV_ENCODER && w && wt && wt->layers && gr && gr->layers && dz && tape && workspace, "encoder_backward: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Tape t = carve_tape(d, b, (char*)tape);
+  BwdWs ws = carve_bwd(d, b, (char*)workspace);
+  TTV_CHECK_ARG(ws.total <= workspace_bytes, "encoder_backward: workspace too small");
+  const int L = b->total_rows, dm = d->width, dt = d->dtype, P = b->sum_patches, K = b->sum_tokens, C = d->token_size;
+  const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  // ---- tail: z = proj_out(n) + b, n = ln_post(X_last[latent rows]) ----
+  TTV_TRY(ttvk_rmsnorm(t.X[d->layers], dt, dm, b->latent_rows, ws.g_d, dt, dm, nullptr, w->ln_post, K, dm, d->eps, s));   // n
+  TTV_TRY(ttvk_outer_small(dz, TTV_F32, C, C, ws.g_d, dt, dm, nullptr, gr->proj_out_w, dm, 0, K, dm, s));
+  TTV_TRY(ttvk_colsum(dz, TTV_F32, C, nullptr, K, C, gr->proj_out_b, s));
+  TTV_TRY(ttvk_expand_small(dz, TTV_F32, C, C, w->proj_out_w, dt, dm, 1, ws.g_d2, dt, dm, K, dm, s));                      // dn
+  (void)hipMemsetAsync(ws.dxa, 0, (size_t)L * dm * sizeof(float), s);
+  TTV_TRY(ttvk_rmsnorm_bwd(t.X[d->layers], dt, dm, b->latent_rows, ws.g_d2, dt, dm, nullptr, w->ln_post, ws.dxa, TTV_F32, dm, b->latent_rows, 0, gr->ln_post, K, dm, d->eps, s));
+  TTV_TRY(layers_backward(d, w, wt, b, t, gr, ws, s));
+  // ---- head ----
+  // latent rows are the constant vector ln_pre_t(mask_token * 1)
+  (void)hipMemsetAsync(ws.colsum, 0, dm * sizeof(float), s);
+  TTV_TRY(ttvk_colsum(ws.dxa, TTV_F32, dm, b->latent_rows, K, dm, ws.colsum, s));
+  TTV_TRY(ttvk_const_rows_bwd(ws.colsum, w->mask_token, w->ln_pre_t, dt, d->eps, gr->ln_pre_t, gr->mask_token, dm, s));
+  // patch rows: X0[patch] = ln_pre_p(pe), pe = proj_in(patches) + bias + mask_token
+  TTV_TRY(ttvk_rmsnorm_bwd(t.pe, dt, dm, nullptr, ws.dxa, TTV_F32, dm, b->patch_rows, w->ln_pre_p, ws.g_d, dt, dm, nullptr, 0, gr->ln_pre_p, P, dm, d->eps, s));  // dpe
+  TTV_TRY(ttvk_sumall(ws.g_d, dt, dm, nullptr, P, dm, nullptr, 1.f, gr->mask_token, s));
+  TTV_TRY(ttvk_colsum(ws.g_d, dt, dm, nullptr, P, dm, gr->proj_in_b, s));
+  TTV_TRY(ttvk_wgrad(ws.g_d, dm, t.patches, pd, gr->proj_in_w, pd, P, dm, pd, dt, s));
+  if (dclips) {
+    GemmArgs a = {};
+    a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = wt->proj_in_t; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.g_pd; a.ldy = pd;
+    TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+    for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+      const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+      TTV_TRY(ttvk_patch_copy(true, dclips + c0, b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.g_pd, pd, dt, b->max_patches_per_clip, s));
+    }
+  }
+  return TTV_OK;
+}
+
+int ttv_decoder_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const void* codes, void* const* clips_out,
+                              void* tape, int64_t tape_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTV_TRY(check(d, b));
+  TTV_CHECK_ARG(d->kind == TTV_DECODER && w && w->layers && codes && clips_out && tape && workspace, "decoder_forward_train: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Tape t = carve_tape(d, b, (char*)tape);
+  TTV_CHECK_ARG(t.total <= tape_bytes, "decoder_forward_train: tape too small");
+  const int dm = d->width, dt = d->dtype, P = b->sum_patches;
+  const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  TTV_CHECK_ARG((int64_t)P * pd * esz(dt) <= workspace_bytes, "decoder_forward_train: workspace too small");
+  TTV_TRY(ttvk_dec_embed_ex(codes, d->token_size, w->proj_in_w, w->proj_in_b, w->mask_token, w->ln_pre_t, t.X[0], dt, dm, b->latent_rows, b->sum_tokens, dm, d->eps, t.hpre, s));
+  TTV_TRY(ttvk_fill_const_rows(t.X[0], dt, dm, b->patch_rows, P, dm, w->mask_token, w->ln_pre_p, d->eps, s));
+  TTV_TRY(layers_forward_train(d, w, b, t, s));
+  TTV_TRY(ttvk_rmsnorm(t.X[d->layers], dt, dm, b->patch_rows, t.pn, dt, dm, nullptr, w->ln_post, P, dm, d->eps, s));
+  GemmArgs a = {};
+  a.dtype = dt; a.x = t.pn; a.ldx = dm; a.w = w->proj_out_w; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = workspace; a.ldy = pd;
+  a.bias = w->proj_out_b;
+  TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+  for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_patch_copy(true, clips_out + c0, b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, workspace, pd, dt, b->max_patches_per_clip, s));
+  }
+  return TTV_OK;
+}
+
+int ttv_decoder_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* b, const void* codes,
+                         const void* const* dclips_out, void* tape, const ttv_tower_grads* gr, float* dcodes, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  TTV_TRY(check(d, b));
+  TTV_CHECK_ARG(d->kind == TTV_DECODER && w && wt && wt->layers && gr && gr->layers && codes && dclips_out && tape && workspace, "decoder_backward: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Tape t = carve_tape(d, b, (char*)tape);
+  BwdWs ws = carve_bwd(d, b, (char*)workspace);
+  TTV_CHECK_ARG(ws.total <= workspace_bytes, "decoder_backward: workspace too small");
+  const int L = b->total_rows, dm = d->width, dt = d->dtype, P = b->sum_patches, K = b->sum_tokens, C = d->token_size;
+  const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
+  // ---- tail: clips = unpatch(proj_out(pn) + bias), pn = ln_post(X_last[patch rows]) ----
+  for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_patch_copy(false, (void* const*)(dclips_out + c0), b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.g_pd, pd, dt, b->max_patches_per_clip, s));
+  }
+  TTV_TRY(ttvk_colsum(ws.g_pd, dt, pd, nullptr, P, pd, gr->proj_out_b, s));
+  TTV_TRY(ttvk_wgrad(ws.g_pd, pd, t.pn, dm, gr->proj_out_w, dm, P, pd, dm, dt, s));
+  GemmArgs a = {};
+  a.dtype = dt; a.x = ws.g_pd; a.ldx = pd; a.w = wt->proj_out_t; a.ldw = pd; a.M = P; a.N = dm; a.K = pd; a.y = ws.g_d2; a.ldy = dm;   // dpn
+  TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
+  (void)hipMemsetAsync(ws.dxa, 0, (size_t)L * dm * sizeof(float), s);
+  TTV_TRY(ttvk_rmsnorm_bwd(t.X[d->layers], dt, dm, b->patch_rows, ws.g_d2, dt, dm, nullptr, w->ln_post, ws.dxa, TTV_F32, dm, b->patch_rows, 0, gr->ln_post, P, dm, d->eps, s));
+  TTV_TRY(layers_backward(d, w, wt, b, t, gr, ws, s));
+  // ---- head ----
+  (void)hipMemsetAsync(ws.colsum, 0, dm * sizeof(float), s);
+  TTV_TRY(ttvk_colsum(ws.dxa, TTV_F32, dm, b->patch_rows, P, dm, ws.colsum, s));
+  TTV_TRY(ttvk_const_rows_bwd(ws.colsum, w->mask_token, w->ln_pre_p, dt, d->eps, gr->ln_pre_p, gr->mask_token, dm, s));
+  // latent rows: X0[latent] = ln_pre_t(hpre), hpre = proj_in(codes) + bias + mask_token
+  TTV_TRY(ttvk_rmsnorm_bwd(t.hpre, dt, dm, nullptr, ws.dxa, TTV_F32, dm, b->latent_rows, w->ln_pre_t, ws.small_f32, TTV_F32, dm, nullptr, 0, gr->ln_pre_t, K, dm, d->eps, s));  // dh
+  TTV_TRY(ttvk_sumall(ws.small_f32, TTV_F32, dm, nullptr, K, dm, nullptr, 1.f, gr->mask_token, s));
+  TTV_TRY(ttvk_colsum(ws.small_f32, TTV_F32, dm, nullptr, K, dm, gr->proj_in_b, s));
+  TTV_TRY(ttvk_outer_small(codes, dt, C, C, ws.small_f32, TTV_F32, dm, nullptr, gr->proj_in_w, C, 1, K, dm, s));
+  if (dcodes) TTV_TRY(ttvk_reduce_small(ws.small_f32, TTV_F32, dm, nullptr, w->proj_in_w, dt, C, C, dcodes, C, K, dm, s));
+  return TTV_OK;
+}
+
+int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype, void* stream) {
+  TTV_CHECK_ARG(L == 0 || (dy && x && dw), "linear_wgrad: null buffer");
+  return ttvk_wgrad(dy, lddy, x, ldx, dw, lddw, L, N, K, dtype, (hipStream_t)stream);
+}
+
+int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const float* gain, void* dx, int lddx, float* dgain, int rows,
+                         int width, float eps, int dtype, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (x && dy && gain && dx), "rmsnorm_backward: null buffer");
+  return ttvk_rmsnorm_bwd(x, dtype, ldx, nullptr, dy, dtype, lddy, nullptr, gain, dx, dtype, lddx, nullptr, 0, dgain, rows, width, eps, (hipStream_t)stream);
+}
+
+int ttv_attention_backward(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
+                           const int32_t* cu_seqlens, const int32_t* blocks64, int n_blocks64, const int32_t* row_seq, void* dqkvg,
+                           int ldg, float* dkv_scratch, int total_rows, int q_heads, int kv_heads, int dtype, void* stream) {
+  TTV_CHECK_ARG(total_rows == 0 || (qkvg && o && dout && lse && delta && cu_seqlens && blocks64 && dqkvg), "attention_backward: null buffer");
+  return ttvk_attention_bwd(qkvg, ld, o, ldo, dout, ldd, lse, delta, cu_seqlens, blocks64, n_blocks64, row_seq, dqkvg, ldg, dkv_scratch,
+                            total_rows, q_heads, kv_heads, dtype, (hipStream_t)stream);
+}
+
+int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
+                      int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, float* lse, void* stream) {
+  TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention_lse: null buffer");
+  return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, gate_mul, dtype, (hipStream_t)stream, lse);
+}
+
+}  // extern "C"

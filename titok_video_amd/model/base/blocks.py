@@ -114,6 +114,74 @@ class _Tower(nn.Module):
     def _plan(self, pixel_grids, token_counts, device) -> BatchPlan:
         return get_plan(pixel_grids, token_counts, self.patch, device)
 
+    # ---- training (autograd) support -------------------------------------------------------------
+    def _wants_grad(self, *inputs) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return any(p.requires_grad for p in self.parameters()) or any(getattr(t, "requires_grad", False) for t in inputs)
+
+    def _grad_buffers(self, device):
+        """Zeroed fp32 gradient buffers in the PACKED weight layout + the C struct + per-parameter views."""
+        ml = self.model_layers
+        named = []   # (parameter, packed shape)
+        pd = self.pix_channels * math.prod(self.patch)
+        named.append((self.proj_in.weight, tuple(self.proj_in.weight.shape)))
+        named.append((self.proj_in.bias, tuple(self.proj_in.bias.shape)))
+        named.append((self.mask_token, (1,)))
+        for m in (self.ln_pre_t, self.ln_pre_p, self.ln_post):
+            named.append((m.weight, (self.width,)))
+        named.append((self.proj_out.weight, tuple(self.proj_out.weight.shape)))
+        named.append((self.proj_out.bias, tuple(self.proj_out.bias.shape)))
+        for i in range(self.num_layers):
+            a, f = ml.attn_layer[i], ml.ffd_layer[i]
+            for prm in (a.pre_ln.weight, a.to_qkv.weight, a.out_proj.weight, f.norm.weight, f.w12.weight, f.w3.weight):
+                named.append((prm, tuple(prm.shape)))
+            if i > 0:
+                named.append((ml.attn_post_ln[i - 1].weight, (self.width,)))
+                named.append((ml.ffd_post_ln[i - 1].weight, (self.width,)))
+        sizes = [int(math.prod(sh)) for _, sh in named]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        flat = torch.zeros(tot, dtype=torch.float32, device=device)
+        views = [flat[o:o + n].view(sh) for o, n, (_, sh) in zip(offs, sizes, named)]
+        ptr = [v.data_ptr() for v in views]
+        lay = (_lib.LayerGrads * self.num_layers)()
+        k = 8
+        for i in range(self.num_layers):
+            fields = dict(pre_ln=ptr[k], to_qkv=ptr[k + 1], out_proj=ptr[k + 2], ffd_norm=ptr[k + 3], w12=ptr[k + 4], w3=ptr[k + 5])
+            k += 6
+            if i > 0:
+                fields.update(attn_post_ln=ptr[k], ffd_post_ln=ptr[k + 1])
+                k += 2
+            lay[i] = _lib.LayerGrads(**fields)
+        st = _lib.TowerGrads(proj_in_w=ptr[0], proj_in_b=ptr[1], mask_token=ptr[2], ln_pre_t=ptr[3], ln_pre_p=ptr[4], ln_post=ptr[5],
+                             proj_out_w=ptr[6], proj_out_b=ptr[7], layers=lay)
+        return flat, views, [p for p, _ in named], st, lay
+
+    def _unpack_grads(self, params, views):
+        """Packed-layout fp32 gradients -> gradients in the reference parameter layout/dtype, keyed by parameter id."""
+        perm = self._patch_perm().to(views[0].device)
+        out = {}
+        for p, g in zip(params, views):
+            if p is self.mask_token:
+                g = g.view(1, 1)
+            elif self.kind == _lib.TTV_ENCODER and p is self.proj_in.weight:
+                r = torch.empty_like(g)
+                r[:, perm] = g
+                g = r
+            elif self.kind == _lib.TTV_DECODER and p is self.proj_out.weight:
+                r = torch.empty_like(g)
+                r[perm, :] = g
+                g = r
+            elif self.kind == _lib.TTV_DECODER and p is self.proj_out.bias:
+                r = torch.empty_like(g)
+                r[perm] = g
+                g = r
+            out[id(p)] = g.to(p.dtype)
+        return out
+
 
 class _WeightPack:
     """Compute-dtype copies of a tower's linear weights (what autocast does per call in the reference), the
@@ -121,10 +189,13 @@ class _WeightPack:
 
     def __init__(self, tower: _Tower, dtype: torch.dtype, device):
         keep: List[torch.Tensor] = []
+        self.dtype, self.device = dtype, device
+        self.lin_tensors: List[torch.Tensor] = []     # compute-dtype linear weights in creation order (see transposed())
 
         def lin(p):
             t = p.detach().to(device=device, dtype=dtype).contiguous()
             keep.append(t)
+            self.lin_tensors.append(t)
             return t.data_ptr()
 
         def gain(p):
@@ -181,6 +252,28 @@ class _WeightPack:
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
             proj_out_w=lin(w_out), proj_out_b=lin(b_out), layers=self.layers)
         self.keep = keep
+        self.kind, self.n_layers = tower.kind, n
+        self._t = None
+
+    def transposed(self) -> "_lib.TowerWeightsT":
+        """W^T copies for the data-gradient GEMMs of the backward pass (built on first use, per weight version)."""
+        if self._t is None:
+            lt = self.lin_tensors   # per layer: to_qkv, out_proj, w12, w3 ; then proj_in_w, proj_in_b, proj_out_w, proj_out_b
+            arr = (_lib.LayerWeightsT * self.n_layers)()
+            keep = []
+
+            def tr(t):
+                u = t.t().contiguous()
+                keep.append(u)
+                return u.data_ptr()
+            for i in range(self.n_layers):
+                q, o, w12, w3 = lt[4 * i: 4 * i + 4]
+                arr[i] = _lib.LayerWeightsT(to_qkv_t=tr(q), out_proj_t=tr(o), w12_t=tr(w12), w3_t=tr(w3))
+            proj_in_w, proj_out_w = lt[4 * self.n_layers], lt[4 * self.n_layers + 2]
+            st = _lib.TowerWeightsT(proj_in_t=tr(proj_in_w) if self.kind == _lib.TTV_ENCODER else None,
+                                    proj_out_t=tr(proj_out_w) if self.kind == _lib.TTV_DECODER else None, layers=arr)
+            self._t = (st, arr, keep)
+        return self._t[0]
 
 
 class TiTokEncoder(_Tower):
@@ -233,9 +326,17 @@ class TiTokEncoder(_Tower):
         _lib.check(rc, "ttv_encoder_forward")
         return {"z": z, "codes": codes, "indices": indices, "bounded": bounded}
 
+    def forward_z(self, videos, token_counts, grids=None) -> torch.Tensor:
+        """fp32 pre-quantisation tokens [sum(K), out_channels]; differentiable when grad is enabled (training step)."""
+        if self._wants_grad(*videos):
+            counts = host_ints(token_counts)
+            pix = [tuple(v.shape[1:]) for v in videos] if grids is None else [tuple(int(x) for x in g) for g in host_ints(grids)]
+            params = list(self.parameters())
+            return _EncoderTrainFn.apply(self, counts, pix, len(videos), *videos, *params)
+        return self.run(videos, token_counts, grids, None, want_z=True)["z"]
+
     def forward(self, videos, token_counts, grids=None):
-        out = self.run(videos, token_counts, grids, None, want_z=True)
-        return out["z"].to(videos[0].dtype)
+        return self.forward_z(videos, token_counts, grids).to(videos[0].dtype)
 
 
 class TiTokDecoder(_Tower):
@@ -257,6 +358,11 @@ class TiTokDecoder(_Tower):
 
     def forward(self, tokens: torch.Tensor, token_counts, grids):
         _lib.require_gpu(tokens, "TiTokDecoder")
+        if self._wants_grad(tokens):
+            counts = host_ints(token_counts)
+            pix = [tuple(int(v) for v in g) for g in host_ints(grids)]
+            outs = _DecoderTrainFn.apply(self, counts, pix, tokens, *list(self.parameters()))
+            return list(outs)
         device, dtype = tokens.device, tokens.dtype
         code = _lib.dtype_code(dtype)
         counts = host_ints(token_counts)
@@ -279,3 +385,93 @@ class TiTokDecoder(_Tower):
                                             _lib.ptr_array(outs), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_decoder_forward")
         return outs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# autograd: tape-recording forward + hand-written HIP backward (csrc/ttv_train.hip, ttv_bwd.hip)
+# ------------------------------------------------------------------------------------------------------------------
+def _train_ctx(tower: _Tower, pix, counts, device, dtype):
+    plan = tower._plan(pix, counts, device)
+    dims = tower._dims(_lib.dtype_code(dtype))
+    batch = plan.batch_for(tower.heads[0], tower.heads[1])
+    pack = tower._packed(dtype, device)
+    lib = _lib.lib()
+    tape = torch.empty(int(lib.ttv_tower_tape_bytes(C.byref(dims), C.byref(batch))), dtype=torch.uint8, device=device)
+    return plan, dims, batch, pack, tape
+
+
+class _EncoderTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tower, counts, pix, n_clips, *tensors):
+        clips = [c.contiguous() for c in tensors[:n_clips]]
+        device, dtype = clips[0].device, clips[0].dtype
+        plan, dims, batch, pack, tape = _train_ctx(tower, pix, counts, device, dtype)
+        z = torch.empty((plan.sum_tokens, tower.token_size), dtype=torch.float32, device=device)
+        rc = _lib.lib().ttv_encoder_forward_train(C.byref(dims), C.byref(pack.struct), C.byref(batch), _lib.ptr_array(clips),
+                                                  z.data_ptr(), tape.data_ptr(), tape.numel(), _lib.stream_ptr(device))
+        _lib.check(rc, "ttv_encoder_forward_train")
+        ctx.tower, ctx.plan, ctx.dims, ctx.batch, ctx.pack, ctx.tape = tower, plan, dims, batch, pack, tape
+        ctx.clips = clips
+        ctx.n_clips = n_clips
+        ctx.clip_grad = [bool(t.requires_grad) for t in tensors[:n_clips]]
+        ctx.params = list(tensors[n_clips:])
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        tower, device = ctx.tower, dz.device
+        lib = _lib.lib()
+        flat, views, params, gstruct, _lay = tower._grad_buffers(device)
+        ws = torch.empty(int(lib.ttv_tower_bwd_workspace_bytes(C.byref(ctx.dims), C.byref(ctx.batch))), dtype=torch.uint8, device=device)
+        dclips = None
+        if any(ctx.clip_grad):
+            dclips = [torch.empty_like(c) for c in ctx.clips]
+        rc = lib.ttv_encoder_backward(C.byref(ctx.dims), C.byref(ctx.pack.struct), C.byref(ctx.pack.transposed()), C.byref(ctx.batch),
+                                      dz.contiguous().float().data_ptr(), ctx.tape.data_ptr(), C.byref(gstruct),
+                                      _lib.ptr_array(dclips) if dclips else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
+        _lib.check(rc, "ttv_encoder_backward")
+        by_id = tower._unpack_grads(params, views)
+        clip_grads = [dclips[i] if (dclips and ctx.clip_grad[i]) else None for i in range(ctx.n_clips)]
+        param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
+        ctx.tape = None
+        return (None, None, None, None, *clip_grads, *param_grads)
+
+
+class _DecoderTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tower, counts, pix, tokens, *params):
+        device, dtype = tokens.device, tokens.dtype
+        tokens = tokens.contiguous()
+        plan, dims, batch, pack, tape = _train_ctx(tower, pix, counts, device, dtype)
+        sizes = [tower.out_channels * t * h * w for (t, h, w) in pix]
+        outs = [torch.empty((tower.out_channels, t, h, w), dtype=dtype, device=device) for (t, h, w) in pix]
+        pd = tower.out_channels * math.prod(tower.patch)
+        ws = torch.empty(plan.sum_patches * pd, dtype=dtype, device=device)
+        rc = _lib.lib().ttv_decoder_forward_train(C.byref(dims), C.byref(pack.struct), C.byref(batch), tokens.data_ptr(),
+                                                  _lib.ptr_array(outs), tape.data_ptr(), tape.numel(), ws.data_ptr(),
+                                                  ws.numel() * ws.element_size(), _lib.stream_ptr(device))
+        _lib.check(rc, "ttv_decoder_forward_train")
+        ctx.tower, ctx.plan, ctx.dims, ctx.batch, ctx.pack, ctx.tape = tower, plan, dims, batch, pack, tape
+        ctx.tokens = tokens
+        ctx.tokens_grad = bool(tokens.requires_grad)
+        ctx.params = list(params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dclips):
+        tower, device = ctx.tower, ctx.tokens.device
+        lib = _lib.lib()
+        flat, views, params, gstruct, _lay = tower._grad_buffers(device)
+        ws = torch.empty(int(lib.ttv_tower_bwd_workspace_bytes(C.byref(ctx.dims), C.byref(ctx.batch))), dtype=torch.uint8, device=device)
+        shapes = [(tower.out_channels, t, h, w) for (t, h, w) in ctx.plan.pixel_grids]
+        dcl = [(g if g is not None else torch.zeros(sh, dtype=ctx.tokens.dtype, device=device)).to(ctx.tokens.dtype).contiguous()
+               for g, sh in zip(dclips, shapes)]
+        dcodes = torch.empty((ctx.plan.sum_tokens, tower.token_size), dtype=torch.float32, device=device)
+        rc = lib.ttv_decoder_backward(C.byref(ctx.dims), C.byref(ctx.pack.struct), C.byref(ctx.pack.transposed()), C.byref(ctx.batch),
+                                      ctx.tokens.data_ptr(), _lib.ptr_array(dcl), ctx.tape.data_ptr(), C.byref(gstruct),
+                                      dcodes.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
+        _lib.check(rc, "ttv_decoder_backward")
+        by_id = tower._unpack_grads(params, views)
+        param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
+        ctx.tape = None
+        return (None, None, None, dcodes.to(ctx.tokens.dtype) if ctx.tokens_grad else None, *param_grads)

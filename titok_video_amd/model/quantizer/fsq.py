@@ -65,7 +65,11 @@ class FSQ(nn.Module):
         return codes, indices, b
 
     def forward(self, z: torch.Tensor):
-        """z [rows, C] -> (codes in z.dtype, {'indices': int32 [rows]}) - fsq.py:123-135."""
+        """z [rows, C] -> (codes in z.dtype, {'indices': int32 [rows]}) - fsq.py:123-135.  With grad enabled and a
+        differentiable z the rounding is straight-through (fsq.py:48-51), backward in csrc/ttv_bwd.hip."""
+        if torch.is_grad_enabled() and z.requires_grad:
+            codes, indices = _FsqFn.apply(z, self)
+            return codes, {"indices": indices}
         codes, indices, _ = self._run(z, False)
         return codes, {"indices": indices}
 
@@ -99,3 +103,25 @@ class FSQ(nn.Module):
 
     def indices_to_level_indices(self, indices):
         return (indices.unsqueeze(-1) // self._basis.to(indices.device)) % self._levels.to(indices.device)
+
+
+class _FsqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, fsq):
+        codes, indices, _ = fsq._run(z, False)
+        ctx.fsq = fsq
+        ctx.save_for_backward(z)
+        ctx.mark_non_differentiable(indices)
+        return codes, indices
+
+    @staticmethod
+    def backward(ctx, dcodes, _dindices):
+        (z,) = ctx.saved_tensors
+        fsq = ctx.fsq
+        zf = z.detach().float().contiguous()
+        dcodes = dcodes.contiguous()
+        dz = torch.empty_like(zf)
+        rc = _lib.lib().ttv_fsq_backward(C.byref(fsq.params), zf.data_ptr(), dcodes.data_ptr(), _lib.dtype_code(dcodes.dtype),
+                                         dz.data_ptr(), zf.shape[0], _lib.stream_ptr(z.device))
+        _lib.check(rc, "ttv_fsq_backward")
+        return dz.to(z.dtype), None

@@ -35,6 +35,14 @@ class TiTok(nn.Module):
 
     def encode(self, x, token_counts, grids=None, split_indices=False, want_bounded=False):
         counts = host_ints(token_counts)
+        if self.encoder._wants_grad(*x):
+            # training step (train.py:65-83): differentiable towers (tape + HIP backward) and straight-through FSQ
+            z = self.encoder.forward_z(x, counts, grids)                 # fp32, carries the autograd graph
+            codes, x_dict = self.quantize(z)
+            self.last_bounded = None
+            if split_indices:
+                x_dict["indices"] = torch.split(x_dict["indices"], counts, dim=0)
+            return codes.to(x[0].dtype), x_dict
         out = self.encoder.run(x, counts, grids, self.quantize.params, want_z=False, want_bounded=want_bounded)
         self.last_bounded = out["bounded"]
         indices = out["indices"]

@@ -88,7 +88,10 @@ class BatchPlan:
             T, H, W = self.pixel_grids[b]
             desc[b] = (T, H, W, grids[b][0], grids[b][1], grids[b][2], pbase, 3)
             pbase += sizes[b]
-        parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1)]
+        blocks64 = np.asarray([(b, r0) for b in range(B) for r0 in range(0, cu[b + 1] - cu[b], 64)], dtype=np.int32).reshape(-1, 2)
+        row_seq = np.concatenate([np.full(cu[b + 1] - cu[b], b, dtype=np.int32) for b in range(B)])
+        self.n_blocks64 = int(blocks64.shape[0])
+        parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1), blocks64.reshape(-1), row_seq]
         offs, total = [], 0
         for p in parts:
             offs.append(total)
@@ -105,7 +108,8 @@ class BatchPlan:
             n_clips=B, total_rows=self.total_rows, sum_tokens=self.sum_tokens, sum_patches=self.sum_patches,
             max_patches_per_clip=max(sizes),
             cu_seqlens=base + 4 * offs[0], latent_rows=base + 4 * offs[1], patch_rows=base + 4 * offs[2],
-            clip_desc=base + 4 * offs[3], rope_cs=self.rope_cs.data_ptr())
+            clip_desc=base + 4 * offs[3], rope_cs=self.rope_cs.data_ptr(),
+            blocks64=base + 4 * offs[4], row_seq=base + 4 * offs[5], n_blocks64=self.n_blocks64)
         self._offs = offs
         self._attn = {}
 
