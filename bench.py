@@ -67,7 +67,9 @@ def cpu_baseline(sd, n_sample=4, max_runs=5, budget_s=25.0):
     from oracle import titok_oracle as O
     clips = synthetic_clips([CLIP] * n_sample, seed=1234)
     counts = [K_TOKENS] * n_sample
-    threads = torch.get_num_threads()
+    # many small ops: more threads than ~32 only adds synchronisation cost; use what is fastest and report it
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     times = []
     t_begin = time.perf_counter()
     out = None
