@@ -54,7 +54,7 @@ def allreduce_mean_by_count(grads: Iterable[torch.Tensor], local_count: int, gro
     if ws == 1:
         return int(local_count)
     dev = grads[0].device if grads else torch.device("cpu")
-    cnt = torch.tensor([float(local_count)], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([float(local_count)], dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else dev)
     dist.all_reduce(cnt, group=group)
     total = float(cnt.item())
     bucket: List[torch.Tensor] = []
@@ -65,7 +65,12 @@ def allreduce_mean_by_count(grads: Iterable[torch.Tensor], local_count: int, gro
         if not bucket:
             return
         flat = torch.cat([g.reshape(-1).to(torch.float32) for g in bucket]) * float(local_count)
-        dist.all_reduce(flat, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":     # CPU-side collective (tests); RCCL reduces in place on the GPU
+            host = flat.cpu()
+            dist.all_reduce(host, group=group)
+            flat = host.to(flat.device)
+        else:
+            dist.all_reduce(flat, group=group)
         flat /= total
         off = 0
         for g in bucket:
