@@ -220,3 +220,31 @@ def test_blocks_kat_fp32():
     _lib.check(lib.ttv_linear_geglu(xn.data_ptr(), dm, w[p + "ffd_layer.1.w12.weight"].data_ptr(), dm, h.data_ptr(), I, Lr, I, dm, 1, S), "g")
     _lib.check(lib.ttv_linear(h.data_ptr(), I, w[p + "ffd_layer.1.w3.weight"].data_ptr(), I, None, None, out.data_ptr(), dm, Lr, dm, I, 1, S), "o")
     np.testing.assert_allclose(out.cpu().numpy(), d["ffd1"], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("size", ["small", "base", "large"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_other_model_sizes_match_oracle(size, dtype):
+    """get_model_dims sizes beyond tiny (utils.py:8-23): widths 512/768/1024, GQA 8:2 / 12:4 / 16:4, GEGLU inner 1376 /
+    2048 / 2752 (1376 is not a multiple of the 64-wide feature tiles) - generic (unfused) kernel path vs the CPU oracle."""
+    sd = seeded_titok_state(3, encoder_size=size, decoder_size=size, gain=3.0)
+    m = TiTok(config(enc=size, dec=size))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV, dtype).eval()
+    shapes, counts = [(4, 16, 16), (8, 16, 24)], [3, 6]
+    clips_cpu = synthetic_clips(shapes, seed=13)
+    with torch.no_grad():
+        ref_recon, ref_idx, ref_z, ref_b = O.titok_forward(clips_cpu, counts, sd, LEVELS, size, size)
+        codes, dd = m.encode([c.to(DEV, dtype) for c in clips_cpu], counts, want_bounded=True)
+        recon = m.decode(O.fsq_indices_to_codes(ref_idx, LEVELS).to(DEV, dtype), counts, shapes)   # decoder on the oracle's codes
+    berr = float((m.last_bounded.cpu() - ref_b).abs().max())
+    perr = max(float((r.float().cpu() - rr).abs().max()) for r, rr in zip(recon, ref_recon))
+    scale = max(float(rr.abs().max()) for rr in ref_recon)
+    print(f"{size} {dtype}: max |bounded err| {berr:.2e}, max pixel err {perr:.2e} (pixel scale {scale:.2f})")
+    if dtype == torch.float32:
+        assert torch.equal(dd["indices"].cpu(), ref_idx)
+        assert berr < 2e-3 and perr < 5e-3 * max(1.0, scale)
+    else:
+        safe = O.fsq_margin(ref_b) > berr + 1e-6
+        assert torch.equal(dd["indices"].cpu()[safe], ref_idx[safe])
+        assert berr < 0.6 and perr < 0.08 * max(1.0, scale)
