@@ -248,3 +248,26 @@ def test_other_model_sizes_match_oracle(size, dtype):
         safe = O.fsq_margin(ref_b) > berr + 1e-6
         assert torch.equal(dd["indices"].cpu()[safe], ref_idx[safe])
         assert berr < 0.6 and perr < 0.08 * max(1.0, scale)
+
+
+def test_ragged_dynamic_batches_fp32_match_oracle():
+    """Batches as the reference's loader emits them (token-budget packing, ragged shapes, K ~ U[1,128], device int32
+    token_counts): indices bit-exact vs the oracle, checkpoint-style state dict with the trainer's `model.` prefix."""
+    from titok_video_amd.data import SyntheticClipStream, dynamic_batches
+    sd = seeded_titok_state(0)
+    lightning_style = {"model." + k: v for k, v in sd.items()}
+    m = TiTok(config())
+    m.load_state_dict({k[len("model."):]: v for k, v in lightning_style.items() if k.startswith("model.")}, strict=True)
+    m = m.to(DEV, torch.float32).eval()
+    stream = SyntheticClipStream(min_grid=(4, 32, 32), max_grid=(8, 64, 64), dtype=torch.float32, device=DEV, seed=2, length=7)
+    n = 0
+    for batch in dynamic_batches(stream, (4, 8, 8), (1, 16), 200, seed=4, device=DEV):
+        with torch.no_grad():
+            recon, out = m(batch["video"], batch["token_counts"])
+        counts = batch["token_counts"].tolist()
+        ref_recon, ref_idx, _, _ = O.titok_forward([v.cpu() for v in batch["video"]], counts, sd, LEVELS)
+        assert torch.equal(out["indices"].cpu(), ref_idx)
+        for r, rr in zip(recon, ref_recon):
+            assert float((r.cpu() - rr).abs().max()) < 5e-3
+        n += len(counts)
+    assert n == 7

@@ -50,8 +50,7 @@ __device__ __forceinline__ float gelu_erf_fast(float v) {
   poly *= t;
   const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
   const float erf_abs = 1.0f - poly * e;
-  const float erf_v = v < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * v * (1.0f + erf_v);
+  return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
 __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ float mlp_gelu(float v) {
   poly *= t;
   const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
   const float erf_abs = 1.0f - poly * e;
-  return 0.5f * v * (1.0f + (v < 0.f ? -erf_abs : erf_abs));
+  return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
 template <int NT, bool KEEL>
@@ -157,23 +157,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpDev p) {
         float hv[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (p.debug & 16) {   // ablation: no GELU
-            hv[e] = acc1[2][j][e] * acc1[0][j][e];
-            hv[4 + e] = acc1[3][j][e] * acc1[1][j][e];
-          } else {
-            hv[e] = mlp_gelu(acc1[2][j][e] * rstd[j]) * (acc1[0][j][e] * rstd[j]);
-            hv[4 + e] = mlp_gelu(acc1[3][j][e] * rstd[j]) * (acc1[1][j][e] * rstd[j]);
-          }
+          hv[e] = mlp_gelu(acc1[2][j][e] * rstd[j]) * (acc1[0][j][e] * rstd[j]);
+          hv[4 + e] = mlp_gelu(acc1[3][j][e] * rstd[j]) * (acc1[1][j][e] * rstd[j]);
         }
         hf[j] = (bf16x8){(bf16_t)hv[0], (bf16_t)hv[1], (bf16_t)hv[2], (bf16_t)hv[3],
                          (bf16_t)hv[4], (bf16_t)hv[5], (bf16_t)hv[6], (bf16_t)hv[7]};
       }
       // ---- phase 2: y^T += W3panel h^T ----
+      // A fragments are fetched 8 at a time ahead of their MFMAs (one LDS latency per 8 m-tiles, not one per m-tile)
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const bf16x8 a3f = __builtin_bit_cast(bf16x8, w3l[kq * 256 + m * 16 + l15]);
+      for (int mg = 0; mg < 2; ++mg) {
+        bf16x8 a3f[8];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3f, hf[j], out[m][j], 0, 0, 0);
+        for (int m = 0; m < 8; ++m) a3f[m] = __builtin_bit_cast(bf16x8, w3l[kq * 256 + (mg * 8 + m) * 16 + l15]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) out[mg * 8 + m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3f[m], hf[j], out[mg * 8 + m][j], 0, 0, 0);
       }
       if (pn + 1 < np && !(p.debug & 2)) LSTORE_PANELS(buf ^ 1);
       __syncthreads();
