@@ -187,6 +187,12 @@ typedef struct ttv_batch {
   int32_t n_blocks64;
 } ttv_batch;
 
+/* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =
+ * cos/sin(inv_freq[f] * n), evaluated once on the host in fp64 exactly as rope.py:40-54 (position ids are small integers,
+ * rope.py:59-67: latent i -> (i,i,i); patch (t,h,w) -> (t,h,w) + K).  Replaces RoPE.forward's per-sample loop (rope.py:57-71). */
+int ttv_rope_table_build(const float* base_cos, const float* base_sin, int n_ids, int n_freqs, const int32_t* clip_desc,
+                         const int32_t* cu_seqlens, const int32_t* row_seq, float* rope_cs, int total_rows, void* stream);
+
 /* bytes of scratch a tower forward needs for this batch */
 int64_t ttv_tower_workspace_bytes(const ttv_tower_dims* dims, const ttv_batch* batch);
 

@@ -115,6 +115,7 @@ SYMBOLS = {
                                          C.c_int, C.c_int, C.c_int, vp]),
     "ttv_attention_lse": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
+    "ttv_rope_table_build": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "ttv_debug_set": (C.c_int, [C.c_int]),
     "ttv_prof_begin": (C.c_int, [C.c_int, C.c_int]),
     "ttv_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -316,6 +316,13 @@ int ttv_decoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
   return TTV_OK;
 }
 
+int ttv_rope_table_build(const float* base_cos, const float* base_sin, int n_ids, int n_freqs, const int32_t* clip_desc, const int32_t* cu_seqlens,
+                         const int32_t* row_seq, float* rope_cs, int total_rows, void* stream) {
+  TTV_CHECK_ARG(total_rows == 0 || (base_cos && base_sin && clip_desc && cu_seqlens && row_seq && rope_cs), "rope_table_build: null buffer");
+  TTV_CHECK_ARG(n_freqs >= 1 && 3 * n_freqs <= 32 && n_ids >= 1, "rope_table_build: bad table shape");
+  return ttvk_rope_build(base_cos, base_sin, n_ids, n_freqs, clip_desc, cu_seqlens, row_seq, rope_cs, total_rows, (hipStream_t)stream);
+}
+
 int ttv_debug_set(int flags) {
   g_ttv_debug = flags;
   return TTV_OK;

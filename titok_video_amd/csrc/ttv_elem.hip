@@ -481,3 +481,45 @@ int ttvk_const_rows_bwd(const float* colsum, const float* mask_token, const floa
   TTV_CHECK_LAUNCH("const_rows_bwd");
   return TTV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// RoPE table of a packed batch, gathered on the device from the host-evaluated base table
+// base_cos/base_sin fp32 [n_ids, F] = cos/sin(inv_freq[f] * n) (fp64 on the host, rope.py:40-54).  Row ids (rope.py:59-67):
+// latent i -> (i,i,i); patch (t,h,w) -> (t,h,w) + K.  out [L,64] = cos[32] | sin[32], column f*3 + axis, tail (1, 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rope_build(const float* __restrict__ base_cos, const float* __restrict__ base_sin, int n_ids,
+                                                    int F, const int* __restrict__ clip_desc, const int* __restrict__ cu,
+                                                    const int* __restrict__ row_seq, float* __restrict__ out, int total_rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_rows * 32) return;
+  const int row = i >> 5, j = i & 31;
+  const int b = row_seq[row];
+  const int* ds = clip_desc + b * 8;
+  const int gh = ds[4], gw = ds[5];
+  const int P = ds[3] * gh * gw, S = cu[b + 1] - cu[b], K = S - P;
+  const int local = row - cu[b];
+  float c = 1.f, sn = 0.f;
+  if (j < 3 * F) {
+    const int f = j / 3, axis = j - 3 * f;
+    int id;
+    if (local < K) id = local;
+    else {
+      const int p = local - K;
+      const int w = p % gw, h = (p / gw) % gh, t = p / (gw * gh);
+      id = (axis == 0 ? t : axis == 1 ? h : w) + K;
+    }
+    id = id < n_ids ? id : n_ids - 1;
+    c = base_cos[id * F + f];
+    sn = base_sin[id * F + f];
+  }
+  out[(size_t)row * 64 + j] = c;
+  out[(size_t)row * 64 + 32 + j] = sn;
+}
+
+int ttvk_rope_build(const float* base_cos, const float* base_sin, int n_ids, int F, const int* clip_desc, const int* cu, const int* row_seq,
+                    float* out, int total_rows, hipStream_t s) {
+  if (total_rows == 0) return TTV_OK;
+  hipLaunchKernelGGL(k_rope_build, dim3(ttv_cdiv(total_rows * 32, 256)), dim3(256), 0, s, base_cos, base_sin, n_ids, F, clip_desc, cu, row_seq, out, total_rows);
+  TTV_CHECK_LAUNCH("rope_build");
+  return TTV_OK;
+}

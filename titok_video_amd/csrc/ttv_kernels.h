@@ -93,3 +93,5 @@ int ttvk_dec_embed_ex(const void* codes, int C, const void* w, const void* bias,
                       int dtype, int ld, const int* rows_map, int rows, int d, float eps, void* hpre, hipStream_t s);
 int ttvk_const_rows_bwd(const float* colsum, const float* mask_token, const float* gain, int dt, float eps, float* dgain, float* dmask,
                         int d, hipStream_t s);
+int ttvk_rope_build(const float* base_cos, const float* base_sin, int n_ids, int F, const int* clip_desc, const int* cu, const int* row_seq,
+                    float* out, int total_rows, hipStream_t s);

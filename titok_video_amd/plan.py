@@ -23,25 +23,47 @@ from . import _lib
 QBLOCK = 128  # query rows per attention workgroup (csrc/ttv_attn.hip QB)
 
 
-@functools.lru_cache(maxsize=256)
-def _rope_clip_table(grid: Tuple[int, ...], k: int, head_dim: int, theta: float = 10000.0) -> np.ndarray:
-    """fp32 [K+P, 64] = cos[32] | sin[32] for one clip; pairs beyond 3*F keep (1, 0) (rope.py:24 leaves them alone)."""
-    nd = len(grid)
+@functools.lru_cache(maxsize=8)
+def _rope_base_table(head_dim: int, nd: int, n_ids: int, theta: float = 10000.0):
+    """fp32 cos/sin of inv_freq[f] * n for every integer position id n < n_ids, evaluated exactly like the reference
+    (rope.py:40-54: fp64 `theta**linspace(0,1,F) * pi/2`, fp64 product with the id, torch.polar, cast to fp32).  Position
+    ids are small integers (latent index, or grid coordinate + token count), so every table entry the reference computes
+    per row is one of these n_ids * F values - rows are gathered from here instead of re-evaluating fp64 trigonometry."""
     f = head_dim // (2 * nd)
     inv = torch.pow(theta, torch.linspace(0.0, 1.0, f, dtype=torch.float64)) * torch.pi / 2.0
-    tok = torch.arange(k, dtype=torch.float32).unsqueeze(-1).expand(-1, nd)
-    coords = [torch.arange(int(g), dtype=torch.float32) for g in grid]
-    gid = torch.cartesian_prod(*coords) + k
-    if gid.dim() == 1:
-        gid = gid.unsqueeze(-1)
-    ids = torch.cat([tok, gid], dim=0)
-    ang = (inv.view(1, -1, 1) * ids.to(torch.float64).unsqueeze(-2)).reshape(ids.shape[0], -1)
+    ids = torch.arange(n_ids, dtype=torch.float32).to(torch.float64)
+    ang = ids.view(-1, 1) * inv.view(1, -1)                       # [n_ids, F]; same fp64 product as inv * id
     fc = torch.polar(torch.ones(1, dtype=torch.float64), ang)
+    return fc.real.to(torch.float32).numpy(), fc.imag.to(torch.float32).numpy()
+
+
+@functools.lru_cache(maxsize=16)
+def _rope_base_device(head_dim: int, nd: int, n_ids: int, device: str):
+    c, s_ = _rope_base_table(head_dim, nd, n_ids)
+    return torch.from_numpy(c).to(device).contiguous(), torch.from_numpy(s_).to(device).contiguous()
+
+
+def _rope_clip_table(grid: Tuple[int, ...], k: int, head_dim: int) -> np.ndarray:
+    """fp32 [K+P, 64] = cos[32] | sin[32] for one clip; pairs beyond 3*F keep (1, 0) (rope.py:24 leaves them alone).
+    Row ids: latent i -> (i,i,i); patch (t,h,w) -> (t,h,w) + K (rope.py:59-67); column f*nd + axis (interleaved)."""
+    nd = len(grid)
+    f = head_dim // (2 * nd)
     half = head_dim // 2
-    out = np.zeros((ids.shape[0], 2 * half), dtype=np.float32)
+    n_ids = 1
+    while n_ids < k + max(grid) + 1:
+        n_ids *= 2
+    n_ids = max(n_ids, 512)
+    cos_t, sin_t = _rope_base_table(head_dim, nd, n_ids)
+    p = int(np.prod(grid))
+    ids = np.empty((k + p, nd), dtype=np.int64)
+    ids[:k] = np.arange(k)[:, None]
+    coords = np.indices(grid).reshape(nd, -1).T                     # raster order == torch.cartesian_prod
+    ids[k:] = coords + k
+    out = np.zeros((k + p, 2 * half), dtype=np.float32)
     out[:, :half] = 1.0
-    out[:, : nd * f] = fc.real.to(torch.float32).numpy()
-    out[:, half: half + nd * f] = fc.imag.to(torch.float32).numpy()
+    # out[row, f*nd + axis] = table[ids[row, axis], f]
+    out[:, : nd * f] = cos_t[ids].transpose(0, 2, 1).reshape(k + p, nd * f)
+    out[:, half: half + nd * f] = sin_t[ids].transpose(0, 2, 1).reshape(k + p, nd * f)
     return out
 
 
@@ -100,10 +122,22 @@ class BatchPlan:
         for o, p in zip(offs, parts):
             host[o:o + p.size] = p
         self.int_tables = torch.from_numpy(host).to(self.device, non_blocking=False)
-        rope = np.concatenate([_rope_clip_table(g, k, head_dim) for g, k in zip(grids, self.token_counts)], axis=0)
-        self.rope_cs = torch.from_numpy(rope).to(self.device)
-
         base = self.int_tables.data_ptr()
+        if self.device.type == "cuda":
+            # gather on the device from the (cached, device-resident) base table: no per-batch trigonometry, no big upload
+            n_ids = 512
+            while n_ids < max(k + max(g) for g, k in zip(grids, self.token_counts)) + 1:
+                n_ids *= 2
+            bc, bs = _rope_base_device(head_dim, len(self.patch), n_ids, str(self.device))
+            self.rope_cs = torch.empty((self.total_rows, head_dim), dtype=torch.float32, device=self.device)
+            rc = _lib.lib().ttv_rope_table_build(bc.data_ptr(), bs.data_ptr(), n_ids, bc.shape[1], base + 4 * offs[3], base + 4 * offs[0],
+                                                 base + 4 * offs[5], self.rope_cs.data_ptr(), self.total_rows,
+                                                 _lib.stream_ptr(self.device))
+            _lib.check(rc, "ttv_rope_table_build")
+        else:   # host tensors (CPU-side tests of the plan): same table, gathered with numpy
+            rope = np.concatenate([_rope_clip_table(g, k, head_dim) for g, k in zip(grids, self.token_counts)], axis=0)
+            self.rope_cs = torch.from_numpy(rope).to(self.device)
+
         self._base_fields = dict(
             n_clips=B, total_rows=self.total_rows, sum_tokens=self.sum_tokens, sum_patches=self.sum_patches,
             max_patches_per_clip=max(sizes),
