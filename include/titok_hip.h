@@ -90,7 +90,7 @@ int ttv_linear_residual(const void* x, int ldx, const void* w, int ldw, const vo
 
 /* The whole KEEL step of one sub-layer (transformer.py:141-142 / 144-145) in one kernel:
  * y = RMSNorm(alpha*resid + x@w^T) * gain, stored in dtype (y may alias resid).  Returns TTV_ERR_UNSUPPORTED unless a
- * full-row kernel exists for the shape (bf16, N == K == 256); callers then use ttv_linear_residual + ttv_rmsnorm. */
+ * full-row kernel exists for the shape (bf16, N == 256, K % 8 == 0); callers then use ttv_linear_residual + ttv_rmsnorm. */
 int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, const void* resid, int ldr, float alpha,
                              const float* gain, float eps, void* y, int ldy, int M, int N, int K, int dtype, void* stream);
 

@@ -214,9 +214,11 @@ def test_linear_residual(dt, f32out):
 
 
 @pytest.mark.parametrize("M", [1, 63, 64, 200, 4097])
-def test_linear_residual_norm_fused(M):
-    """KEEL step in one kernel (bf16, N = K = 256): y = RMSNorm(alpha*resid + x@w^T)*gain, in place on resid."""
-    N = K = 256
+@pytest.mark.parametrize("K", [256, 704, 1376])
+def test_linear_residual_norm_fused(M, K):
+    """KEEL step in one kernel (bf16, N = 256): y = RMSNorm(alpha*resid + x@w^T)*gain, in place on resid.
+    K = 256: register-resident-token kernel (out_proj); other K: full-row tile kernel (w3)."""
+    N = 256
     x, w, g = _lin_inputs(M, N, K, "bf16", 17 + M)
     r = torch.randn(M, N, generator=g).to(torch.bfloat16)
     gain = 1 + 0.1 * torch.randn(N, generator=g)

@@ -136,6 +136,10 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     if (i == 0) {
       f3.alpha = 1.f; f3.y = ws.x; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
+    } else if (ttvk_gemm_supports_resid_norm(dt, dm, d->inner)) {
+      // x <- RMSNorm(alpha*x + h@W3^T) * gain in one full-row kernel (in place: a token row is read and written by one block)
+      f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
+      TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
       f3.alpha = d->alpha; f3.y = ws.y32; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
@@ -214,7 +218,7 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
   a.dtype = dtype; a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy;
   a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.norm_gain = gain; a.eps = eps;
   if (!ttvk_gemm_supports_resid_norm(dtype, N, K)) {
-    ttv_set_error("linear_residual_norm: only bf16 with N == K == 256 has a fused kernel");
+    ttv_set_error("linear_residual_norm: only bf16 with N == 256 has a fused kernel");
     return TTV_ERR_UNSUPPORTED;
   }
   return ttvk_gemm(EPI_RESID_NORM, a, (hipStream_t)stream);

@@ -598,6 +598,139 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_t
 }
 
 // ================================================================================================
+// Full-row tile kernel, general K, N == 256: y = RMSNorm(alpha*resid + x w^T) * gain   (w3 of a width-256 tower + the
+// KEEL step, transformer.py:55,144-145).  Block = 256 features x 64 tokens, 4 waves each 64 features x 64 tokens
+// (4x4 MFMA tiles), K-tiles of 64 through double-buffered swizzled LDS (W 32 KiB + X 8 KiB per buffer, 2 blocks / CU).
+// Row statistics: in-lane sum over the lane's 16 features per token, xor-16/32 shuffles (wave = 64 features), then a
+// 4-wave reduction through LDS.  Output bf16, 16-byte paired stores; nothing is written in fp32.
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
+  __shared__ uint4 lw[2][256 * 8];   // 2 x 32 KiB
+  __shared__ uint4 lx[2][64 * 8];    // 2 x 8 KiB
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(&lx[0][0]);   // [4][64] row partial sums; aliases lx after the K loop (80 KiB total -> 2 blocks / CU)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int tbase = blockIdx.x * 64;
+  const bf16_t* W = (const bf16_t*)p.w;
+  const bf16_t* X = (const bf16_t*)p.x;
+  // staging: W 2048 chunks (8 per thread: row = (tid>>3) + 32*i, chunk = tid&7), X 512 chunks (2 per thread)
+  const int srow = tid >> 3, skc = tid & 7;
+  int xr0 = tbase + srow, xr1 = tbase + srow + 32;
+  xr0 = xr0 < p.M ? xr0 : p.M - 1;
+  xr1 = xr1 < p.M ? xr1 : p.M - 1;
+  const bf16_t* xp0 = X + (size_t)xr0 * p.ldx + skc * 8;
+  const bf16_t* xp1 = X + (size_t)xr1 * p.ldx + skc * 8;
+  const bf16_t* wp = W + (size_t)srow * p.ldw + skc * 8;
+  uint4 sw0, sw1, sw2, sw3, sw4, sw5, sw6, sw7, sx0, sx1;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+#define RT_GLOAD(k0)                                                                              \
+  do {                                                                                            \
+    const bool ok__ = ((k0) + skc * 8) < p.K;                                                     \
+    const bf16_t* w__ = wp + (k0);                                                                \
+    const size_t st__ = (size_t)32 * p.ldw;                                                       \
+    sw0 = ok__ ? *reinterpret_cast<const uint4*>(w__) : zero4;                                    \
+    sw1 = ok__ ? *reinterpret_cast<const uint4*>(w__ + st__) : zero4;                             \
+    sw2 = ok__ ? *reinterpret_cast<const uint4*>(w__ + 2 * st__) : zero4;                         \
+    sw3 = ok__ ? *reinterpret_cast<const uint4*>(w__ + 3 * st__) : zero4;                         \
+    sw4 = ok__ ? *reinterpret_cast<const uint4*>(w__ + 4 * st__) : zero4;                         \
+    sw5 = ok__ ? *reinterpret_cast<const uint4*>(w__ + 5 * st__) : zero4;                         \
+    sw6 = ok__ ? *reinterpret_cast<const uint4*>(w__ + 6 * st__) : zero4;                         \
+    sw7 = ok__ ? *reinterpret_cast<const uint4*>(w__ + 7 * st__) : zero4;                         \
+    sx0 = ok__ ? *reinterpret_cast<const uint4*>(xp0 + (k0)) : zero4;                             \
+    sx1 = ok__ ? *reinterpret_cast<const uint4*>(xp1 + (k0)) : zero4;                             \
+  } while (0)
+#define RT_IDX(r_) ((r_) * 8 + (skc ^ (((r_) >> 1) & 7)))
+#define RT_LSTORE(buf)                                                                            \
+  do {                                                                                            \
+    lw[buf][RT_IDX(srow)] = sw0; lw[buf][RT_IDX(srow + 32)] = sw1; lw[buf][RT_IDX(srow + 64)] = sw2; lw[buf][RT_IDX(srow + 96)] = sw3;       \
+    lw[buf][RT_IDX(srow + 128)] = sw4; lw[buf][RT_IDX(srow + 160)] = sw5; lw[buf][RT_IDX(srow + 192)] = sw6; lw[buf][RT_IDX(srow + 224)] = sw7; \
+    lx[buf][RT_IDX(srow)] = sx0; lx[buf][RT_IDX(srow + 32)] = sx1;                                \
+  } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = (p.K + BK - 1) / BK;
+  RT_GLOAD(0);
+  RT_LSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) RT_GLOAD((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+      const int kc = ks * 4 + kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int arow = wave * 64 + i * 16 + l15, brow = i * 16 + l15;
+        a[i] = __builtin_bit_cast(bf16x8, lw[buf][arow * 8 + (kc ^ ((arow >> 1) & 7))]);
+        b[i] = __builtin_bit_cast(bf16x8, lx[buf][brow * 8 + (kc ^ ((brow >> 1) & 7))]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) RT_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef RT_GLOAD
+#undef RT_IDX
+#undef RT_LSTORE
+  // ---- epilogue: y = alpha*resid + acc; row sum of squares over all 256 features; scale; gain; store ----
+  float ssq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int t = tbase + j * 16 + l15;
+    t = t < p.M ? t : p.M - 1;
+    const bf16_t* rrow = (const bf16_t*)p.resid + (size_t)t * p.ldr + wave * 64 + kq * 4;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 r = Vec4<bf16_t>::load(rrow + i * 16);
+      acc[i][j] += p.alpha * r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss = fmaf(acc[i][j][e], acc[i][j][e], ss);
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    ssq[j] = ss;
+  }
+  if (kq == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][j * 16 + l15] = ssq[j];
+  }
+  __syncthreads();
+  const bool odd = kq & 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tl = j * 16 + l15, t = tbase + tl;
+    const float tot = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+    const float rstd = 1.0f / sqrtf(tot * (1.0f / 256.0f) + p.eps);
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip) {
+      const int i0 = 2 * ip, i1 = 2 * ip + 1;
+      const int f0 = wave * 64 + i0 * 16 + kq * 4, f1 = wave * 64 + i1 * 16 + kq * 4;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.norm_gain + f0), g1 = *reinterpret_cast<const f32x4*>(p.norm_gain + f1);
+      f32x4 y0, y1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][j][e] * rstd * g0[e]; y1[e] = acc[i1][j][e] * rstd * g1[e]; }
+      const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
+      const uint2 send = odd ? p0 : p1;
+      uint2 recv;
+      recv.x = __shfl_xor(send.x, 16, 64);
+      recv.y = __shfl_xor(send.y, 16, 64);
+      const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+      const int start = odd ? f1 - 4 : f0;
+      if (t < p.M && !(p.debug & 1)) *reinterpret_cast<uint4*>((bf16_t*)p.y + (size_t)t * p.ldy + start) = out;
+    }
+  }
+}
+
+// ================================================================================================
 // fp32 kernel (parity instrument)
 // ================================================================================================
 #define F_TF 64
@@ -690,7 +823,7 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
   return TTV_OK;
 }
 
-bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K) { return dtype == TTV_BF16 && N == 256 && K == 256; }
+bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K) { return dtype == TTV_BF16 && N == 256 && K % 8 == 0; }
 
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   if (a.M == 0 || a.N == 0) return TTV_OK;
@@ -727,12 +860,17 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
       TTV_CHECK_ARG(a.resid && a.ldr % 4 == 0, "gemm: residual missing");
       return launch<EPI_RESID_F32>(d, a.dtype, pn, s);
     case EPI_RESID_NORM: {
-      TTV_CHECK_ARG(ttvk_gemm_supports_resid_norm(a.dtype, a.N, a.K), "gemm: fused residual+norm needs bf16, N == K == 256");
+      TTV_CHECK_ARG(ttvk_gemm_supports_resid_norm(a.dtype, a.N, a.K), "gemm: fused residual+norm needs bf16 and N == 256");
       TTV_CHECK_ARG(a.resid && a.norm_gain && a.ldr % 4 == 0 && a.ldw >= 256, "gemm: residual / gain missing");
       TTV_CHECK_ARG(a.y != a.x, "gemm: fused residual+norm output must not alias the GEMM input");
-      const int n_tiles = ttv_cdiv(a.M, ROW_TT);
-      hipLaunchKernelGGL(k_gemm_k256_rownorm, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), 0, s, d, n_tiles);
-      TTV_CHECK_LAUNCH("gemm_k256_rownorm");
+      if (a.K == 256) {
+        const int n_tiles = ttv_cdiv(a.M, ROW_TT);
+        hipLaunchKernelGGL(k_gemm_k256_rownorm, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), 0, s, d, n_tiles);
+        TTV_CHECK_LAUNCH("gemm_k256_rownorm");
+      } else {
+        hipLaunchKernelGGL(k_gemm_rowtile_norm, dim3(ttv_cdiv(a.M, 64)), dim3(256), 0, s, d);
+        TTV_CHECK_LAUNCH("gemm_rowtile_norm");
+      }
       return TTV_OK;
     }
   }

@@ -76,6 +76,8 @@ for dbg in ([0, 1] if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
     w3pp = rnd(d, I, scale=I ** -0.5)
     timeit("fused MLP (w12+geglu+w3+keel+norm)", lambda: lib.ttv_mlp_fused(x.data_ptr(), d, w12.data_ptr(), w3pp.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, S),
            2.0 * L * d * 3 * I, L * d * 4)
+    timeit("residual+norm fused K704 N256 (rowtile)", lambda: lib.ttv_linear_residual_norm(h.data_ptr(), I, w3.data_ptr(), I, yb.data_ptr(), d, 8.0, gain.data_ptr(), 1e-5, yb.data_ptr(), d, L, d, I, 0, S),
+           2.0 * L * I * d, L * (I * 2 + d * 4))
     if QUICK:
         continue
     timeit("residual bf16-out K256 N256 (k256)", lambda: lib.ttv_linear_residual(x.data_ptr(), d, wo.data_ptr(), d, x.data_ptr(), d, 1.0, yb.data_ptr(), d, 0, L, d, d, 0, S),
