@@ -165,6 +165,8 @@ class _Tower(nn.Module):
         perm = self._patch_perm().to(views[0].device)
         out = {}
         for p, g in zip(params, views):
+            if g.dtype != p.dtype:
+                raise AssertionError("convert the flat buffer first (see _convert_views)")
             if p is self.mask_token:
                 g = g.view(1, 1)
             elif self.kind == _lib.TTV_ENCODER and p is self.proj_in.weight:
@@ -179,8 +181,18 @@ class _Tower(nn.Module):
                 r = torch.empty_like(g)
                 r[perm] = g
                 g = r
-            out[id(p)] = g.to(p.dtype)
+            out[id(p)] = g
         return out
+
+    @staticmethod
+    def _convert_views(flat: torch.Tensor, views, params):
+        """One cast of the whole flat fp32 gradient buffer to the parameter dtype (instead of one tiny kernel per parameter)."""
+        dt = params[0].dtype
+        if dt == torch.float32:
+            return views
+        conv = flat.to(dt)
+        base = flat.data_ptr()
+        return [conv[(v.data_ptr() - base) // 4: (v.data_ptr() - base) // 4 + v.numel()].view(v.shape) for v in views]
 
 
 class _WeightPack:
@@ -430,7 +442,7 @@ class _EncoderTrainFn(torch.autograd.Function):
                                       dz.contiguous().float().data_ptr(), ctx.tape.data_ptr(), C.byref(gstruct),
                                       _lib.ptr_array(dclips) if dclips else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_encoder_backward")
-        by_id = tower._unpack_grads(params, views)
+        by_id = tower._unpack_grads(params, tower._convert_views(flat, views, params))
         clip_grads = [dclips[i] if (dclips and ctx.clip_grad[i]) else None for i in range(ctx.n_clips)]
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None
@@ -471,7 +483,7 @@ class _DecoderTrainFn(torch.autograd.Function):
                                       ctx.tokens.data_ptr(), _lib.ptr_array(dcl), ctx.tape.data_ptr(), C.byref(gstruct),
                                       dcodes.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_decoder_backward")
-        by_id = tower._unpack_grads(params, views)
+        by_id = tower._unpack_grads(params, tower._convert_views(flat, views, params))
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None
         return (None, None, None, dcodes.to(ctx.tokens.dtype) if ctx.tokens_grad else None, *param_grads)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Training-step timing at the benchmark shape (32 x 16x128x128 clips, K=128, bf16): forward (tape) + L1 + backward + AdamW."""
+import json, os, sys, time
+from types import SimpleNamespace
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from titok_video_amd.model.titok import TiTok
+from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
+from titok_video_amd.train import make_optimizer, training_step
+B = int(os.environ.get("B", "32"))
+cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5], encoder_size="tiny", decoder_size="tiny")))
+m = TiTok(cfg); m.load_state_dict(seeded_titok_state(0)); m = m.to("cuda:0", torch.bfloat16).train()
+clips = synthetic_clips([(16, 128, 128)] * B, seed=1, dtype=torch.bfloat16, device="cuda:0")
+counts = [128] * B
+opt = make_optimizer(m)
+for _ in range(3):
+    training_step(m, clips, counts, opt)
+torch.cuda.synchronize()
+n = int(os.environ.get("STEPS", "10"))
+t0 = time.perf_counter()
+for _ in range(n):
+    loss, gn, _ = training_step(m, clips, counts, opt)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(json.dumps({"train_ms_per_step": 1e3 * dt, "clips_per_s": B / dt, "batch": B, "loss": float(loss)}))
