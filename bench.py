@@ -104,12 +104,18 @@ def main():
     distributed = world > 1
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal switch for boxes with fewer GPUs than ranks (CPU-side collective, every rank on cuda:0); never set by the driver
+    rehearsal = os.environ.get("TTV_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
 
     sd = seeded_titok_state(0)
     model = TiTok(tiny_config())
@@ -141,7 +147,7 @@ def main():
         _lib.check(lib.ttv_prof_end(C.byref(tot_ms), C.byref(cnt)), "prof_end")
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
