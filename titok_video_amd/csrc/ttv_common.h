@@ -86,3 +86,28 @@ struct TtvProfScope {
 };
 
 static inline int ttv_cdiv(int a, int b) { return (a + b - 1) / b; }
+// bf16 path: gelu(g) * x for two elements at once, transcendental-free so that it runs on the packed-fp32 VALU
+// (v_pk_fma_f32: 2 lanes-worth per issue).  Phi(v) - 1/2 = t * Q(u), t = clamp(v, -5, 5) / 5, u = 2 t^2 - 1 in [-1, 1],
+// Q a degree-10 minimax fit (coefficients O(1): no cancellation in fp32 Horner).  max |gelu - exact| = 1.1e-5 over all v,
+// i.e. 1/20 of a bf16 half-ulp at 0.03; the fp32 parity path uses erff().
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 geglu_pair_fast(f32x2 g, f32x2 x) {
+  const f32x2 vc = {__builtin_amdgcn_fmed3f(g.x, -5.0f, 5.0f), __builtin_amdgcn_fmed3f(g.y, -5.0f, 5.0f)};
+  const f32x2 t = vc * 0.2f;
+  const f32x2 u = __builtin_elementwise_fma(t + t, t, (f32x2)(-1.0f));
+  f32x2 q = (f32x2)(1.138652562e-02f);
+  q = __builtin_elementwise_fma(q, u, (f32x2)(-3.139007089e-02f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(3.510615383e-02f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(-4.164913603e-02f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(7.773959393e-02f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(-1.210758038e-01f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(1.587207418e-01f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(-2.015958492e-01f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(2.574400549e-01f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(-3.515025932e-01f));
+  q = __builtin_elementwise_fma(q, u, (f32x2)(7.068215094e-01f));
+  const f32x2 phi = __builtin_elementwise_fma(t, q, (f32x2)(0.5f));
+  return (g * phi) * x;
+}
+
+

@@ -40,19 +40,6 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16 resolution) for the bf16 GEGLU epilogue:
 // one v_rcp, one v_exp and a degree-5 Horner chain instead of libm's branchy erff.
-__device__ __forceinline__ float gelu_erf_fast(float v) {
-  const float z = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float erf_abs = 1.0f - poly * e;
-  return 0.5f * v * (1.0f + copysignf(erf_abs, v));
-}
-
 __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
   bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
   return __builtin_bit_cast(uint2, b);
@@ -129,10 +116,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
+        if (sizeof(T) == 2) {
+          const f32x2 lo = geglu_pair_fast((f32x2){acc2[i][j][0], acc2[i][j][1]}, (f32x2){acc[i][j][0], acc[i][j][1]});
+          const f32x2 hi = geglu_pair_fast((f32x2){acc2[i][j][2], acc2[i][j][3]}, (f32x2){acc[i][j][2], acc[i][j][3]});
+          acc[i][j] = (f32x4){lo.x, lo.y, hi.x, hi.y};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gl = sizeof(T) == 2 ? gelu_erf_fast(acc2[i][j][e]) : gelu_erf(acc2[i][j][e]);
-          acc[i][j][e] = gl * acc[i][j][e];
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = gelu_erf(acc2[i][j][e]) * acc[i][j][e];
         }
   } else {  // EPI_RESID_T / EPI_RESID_F32
     f32x4 r[NI][NJ];
@@ -345,26 +335,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   const bf16_t* W = (const bf16_t*)p.w;
   const bf16_t* X = (const bf16_t*)p.x;
 
-  // staging: 8 chunks per thread per panel; chunk = tid + 256*i -> row = (tid>>5) + 8*i, ch = tid & 31
-  const int srow = tid >> 5, sch = tid & 31;
-  uint4 st0, st1, st2, st3, st4, st5, st6, st7;
-#define WROW(panel_, i_)                                                                                     \
+  // panel staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction fills 1 KiB = two 512-byte panel rows,
+  // lane-linear in LDS, so the XOR swizzle the fragment reads use is applied to the SOURCE chunk instead
+  // (same involution on both sides).  Wave w stages rows 16w .. 16w+15 (8 instructions), no VGPR staging, no ds_write.
+  const int g_half = lane >> 5, g_c = lane & 31;
+#define WROWIDX(panel_, row_)                                                                                \
   ({                                                                                                         \
-    const int row__ = srow + 8 * (i_);                                                                       \
-    int wr__ = DUAL ? (row__ < 32 ? (panel_) * 32 + row__ : p.N + (panel_) * 32 + (row__ - 32)) : (panel_) * 64 + row__; \
-    wr__ = wr__ < p.w_rows ? wr__ : p.w_rows - 1;                                                            \
-    *reinterpret_cast<const uint4*>(W + (size_t)wr__ * p.ldw + sch * 8);                                     \
+    int wr__ = DUAL ? ((row_) < 32 ? (panel_) * 32 + (row_) : p.N + (panel_) * 32 + ((row_) - 32)) : (panel_) * 64 + (row_); \
+    wr__ < p.w_rows ? wr__ : p.w_rows - 1;                                                                   \
   })
-#define GLOADP(panel_)                                                                                       \
+#define GLDS_PANEL(panel_, buf_)                                                                             \
   do {                                                                                                       \
-    st0 = WROW(panel_, 0); st1 = WROW(panel_, 1); st2 = WROW(panel_, 2); st3 = WROW(panel_, 3);              \
-    st4 = WROW(panel_, 4); st5 = WROW(panel_, 5); st6 = WROW(panel_, 6); st7 = WROW(panel_, 7);              \
+    _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) {                                                    \
+      const int r0__ = wave * 16 + 2 * i__, row__ = r0__ + g_half;                                           \
+      const int ch__ = (g_c & 16) | ((g_c & 15) ^ (row__ & 15));                                             \
+      const bf16_t* src__ = W + (size_t)WROWIDX(panel_, row__) * p.ldw + ch__ * 8;                           \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src__,                 \
+                                       (__attribute__((address_space(3))) void*)&wl[buf_][r0__ * 32], 16, 0, 0); \
+    }                                                                                                        \
   } while (0)
-#define LIDX(i_) ((srow + 8 * (i_)) * 32 + ((sch & 16) | ((sch & 15) ^ ((srow + 8 * (i_)) & 15))))
-#define LSTOREP(buf_)                                                                                        \
+  // A fragments of k-step s8 (4 m-tiles) from panel buffer buf_
+#define LOADA(dst_, buf_, s8_)                                                                               \
   do {                                                                                                       \
-    wl[buf_][LIDX(0)] = st0; wl[buf_][LIDX(1)] = st1; wl[buf_][LIDX(2)] = st2; wl[buf_][LIDX(3)] = st3;      \
-    wl[buf_][LIDX(4)] = st4; wl[buf_][LIDX(5)] = st5; wl[buf_][LIDX(6)] = st6; wl[buf_][LIDX(7)] = st7;      \
+    const int ch__ = (s8_) * 4 + kq;                                                                         \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                    \
+      const int arow__ = i__ * 16 + l15;                                                                     \
+      dst_[i__] = __builtin_bit_cast(bf16x8, wl[buf_][arow__ * 32 + ((ch__ & 16) | ((ch__ & 15) ^ (arow__ & 15)))]); \
+    }                                                                                                        \
+  } while (0)
+#define MFMA8(a_, s8_)                                                                                       \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__)                                                      \
+      _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__)                                                    \
+        acc[i__][j__] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[i__], bfr[j__][s8_], acc[i__][j__], 0, 0, 0); \
   } while (0)
 
   bf16x8 bfr[2][8];
@@ -374,9 +377,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   // token: feature i*16 + kq*4 + {0..3} -> complex pairs i*8 + kq*2 + {0,1}.  Kept in registers per token tile.
   float2 rc[4][2], rs[4][2];
 
-  GLOADP(it0 % n_panels);
-  LSTOREP(0);
+  bf16x8 a0[4], a1[4];
+  GLDS_PANEL(it0 % n_panels, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
+  LOADA(a0, 0, 0);
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
     const int tile = it / n_panels, panel = it - tile * n_panels;
@@ -420,28 +425,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
         }
       }
     }
-    if (it + 1 < it1 && !(p.debug & 2)) GLOADP((it + 1) % n_panels);
+    // next panel -> other buffer, in flight behind the whole MFMA phase (every wave left that buffer before the
+    // previous item's barrier)
+    if (it + 1 < it1 && !(p.debug & 2)) GLDS_PANEL((it + 1) % n_panels, buf ^ 1);
 
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A fragments double-buffered in registers: the reads of k-step s+1 are issued before the 8 MFMAs of k-step s
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) {
-      const int ch = s8 * 4 + kq;
-      bf16x8 a[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int arow = i * 16 + l15;
-        a[i] = __builtin_bit_cast(bf16x8, wl[buf][arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
+    for (int s8 = 0; s8 < 8; s8 += 2) {
+      LOADA(a1, buf, s8 + 1);
+      MFMA8(a0, s8);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the 4 fragment reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs that cover their latency
+      __builtin_amdgcn_sched_barrier(0);
+      if (s8 + 2 < 8) {
+        LOADA(a0, buf, s8 + 2);
+        MFMA8(a1, s8 + 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      } else {
+        MFMA8(a1, s8 + 1);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[j][s8], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (it + 1 < it1 && !(p.debug & 2)) LSTOREP(buf ^ 1);   // waits for the panel loads only: no younger memory op has been issued yet
+    // ONE barrier per item, before the epilogue: next panel landed (vmcnt(0)) and every wave is done with this one;
+    // the waves then run their epilogues unsynchronised, with the first fragments of the next item already requested
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next panel is in LDS
+    __syncthreads();
+    if (it + 1 < it1) LOADA(a0, buf ^ 1, 0);
 
     int tok[2];
 #pragma unroll
@@ -479,12 +494,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
       for (int i = 0; i < 4; ++i) feat[i] = panel * FO + i * 16 + kq * 4;
       epilogue_tile<EPI, bf16_t, 4, 2>(p, tok, feat, acc, acc, kq);
     }
-    __syncthreads();
   }
-#undef WROW
-#undef GLOADP
-#undef LIDX
-#undef LSTOREP
+#undef WROWIDX
+#undef GLDS_PANEL
+#undef LOADA
+#undef MFMA8
 }
 
 // ================================================================================================

@@ -35,20 +35,6 @@ struct MlpDev {
   int M, n_tiles, debug;
 };
 
-__device__ __forceinline__ float mlp_gelu(float v) {
-  // erf by Abramowitz-Stegun 7.1.26 (abs error <= 1.5e-7): h is rounded to bf16 right after
-  const float z = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float erf_abs = 1.0f - poly * e;
-  return 0.5f * v * (1.0f + copysignf(erf_abs, v));
-}
-
 template <int NT, bool KEEL>
 __global__ __launch_bounds__(256, 1) void k_mlp256(MlpDev p) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -156,10 +142,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpDev p) {
       for (int j = 0; j < NT; ++j) {
         float hv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          hv[e] = mlp_gelu(acc1[2][j][e] * rstd[j]) * (acc1[0][j][e] * rstd[j]);
-          hv[4 + e] = mlp_gelu(acc1[3][j][e] * rstd[j]) * (acc1[1][j][e] * rstd[j]);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 gg = (f32x2){acc1[2 + i][j][e], acc1[2 + i][j][e + 1]} * rstd[j];
+            const f32x2 xx = (f32x2){acc1[i][j][e], acc1[i][j][e + 1]} * rstd[j];
+            const f32x2 h2 = geglu_pair_fast(gg, xx);
+            hv[4 * i + e] = h2.x;
+            hv[4 * i + e + 1] = h2.y;
+          }
         hf[j] = (bf16x8){(bf16_t)hv[0], (bf16_t)hv[1], (bf16_t)hv[2], (bf16_t)hv[3],
                          (bf16_t)hv[4], (bf16_t)hv[5], (bf16_t)hv[6], (bf16_t)hv[7]};
       }
