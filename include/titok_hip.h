@@ -96,10 +96,13 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
 
 /* Whole GEGLU sub-layer (transformer.py:47-56) + residual/KEEL step (:130, :144-145) in one kernel, bf16, width 256:
  * y = [RMSNorm](alpha*x + (gelu(xn@w12[I:]^T) * (xn@w12[:I]^T)) @ w3^T) [* post_gain], xn = RMSNorm(x)*norm_gain.
- * w12_folded = w12 * norm_gain[None,:]; w3_perm as in ttv_layer_weights; post_gain NULL = plain residual (layer 0).
+ * mlp_packed = ttv_mlp_pack(w12 * norm_gain[None,:], w3): the per-panel LDS images the kernel streams (built once per
+ * weight version, ttv_mlp_pack_bytes(inner) bytes); post_gain NULL = plain residual (layer 0).
  * y may alias x.  TTV_ERR_UNSUPPORTED for other dtypes/widths. */
-int ttv_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
-                  const float* post_gain, float alpha, float eps, int M, int width, int dtype, void* stream);
+int64_t ttv_mlp_pack_bytes(int inner);
+int ttv_mlp_pack(const void* w12_folded, const void* w3, int inner, int width, int dtype, void* mlp_packed, void* stream);
+int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
+                  float eps, int M, int width, int dtype, void* stream);
 
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
@@ -149,9 +152,8 @@ typedef struct ttv_layer_weights {
    * (w * gain[None,:]); when non-NULL the pre-norm runs inside the GEMM (rstd from the register-resident row) */
   const void* to_qkv_pn;
   const void* w12_pn;
-  /* optional (bf16, width 256): w3 with its columns permuted inside every 32-column panel to the k order of the fused
-   * feed-forward kernel: w3_perm[:, 32p + 8q + j] = w3[:, 32p + (j<4 ? 4q+j : 16+4q+(j-4))] */
-  const void* w3_perm;
+  /* optional (bf16, width 256): ttv_mlp_pack(w12_pn, w3) - panel images of the fused feed-forward kernel */
+  const void* mlp_pack;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {
@@ -289,6 +291,8 @@ int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int c
 int ttv_prof_begin(int kernel_class, int max_records);
 /* Diagnostics for kernel ablation timing (never set in product use): bit0 = GEMM epilogues skip their stores. */
 int ttv_debug_set(int flags);
+/* Diagnostics: device buffer (>= 256 int64) that instrumented kernels fill with s_memtime stamps of block 0; NULL = off. */
+int ttv_debug_stamps(void* device_buffer);
 /* Synchronise the recorded events, return their summed duration (ms) and count, and release them. */
 int ttv_prof_end(double* total_ms, int* count);
 

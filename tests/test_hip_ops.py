@@ -233,16 +233,9 @@ def test_linear_residual_norm_fused(M, K):
     assert rc == 3      # TTV_ERR_UNSUPPORTED: callers fall back to linear_residual + rmsnorm
 
 
-def _w3_perm_cols(I):
-    q = torch.arange(4).view(4, 1)
-    j = torch.arange(8).view(1, 8)
-    within = torch.where(j < 4, 4 * q + j, 16 + 4 * q + (j - 4)).reshape(-1)
-    return (torch.arange(I // 32).view(-1, 1) * 32 + within.view(1, -1)).reshape(-1)
-
-
-@pytest.mark.parametrize("M", [1, 100, 192, 200, 1000])
+@pytest.mark.parametrize("M", [1, 100, 192, 200, 1000, 50000])
 @pytest.mark.parametrize("keel", [True, False])
-@pytest.mark.parametrize("I", [704, 96])
+@pytest.mark.parametrize("I", [704, 96, 32])
 def test_mlp_fused(M, keel, I):
     """Whole GEGLU sub-layer + residual/KEEL in one kernel vs the op-by-op definition (transformer.py:47-56,130,144-145)."""
     d = 256
@@ -253,10 +246,12 @@ def test_mlp_fused(M, keel, I):
     ng = 1 + 0.1 * torch.randn(d, generator=g)
     pg = 1 + 0.1 * torch.randn(d, generator=g)
     w12f = (w12.float() * ng[None, :]).to(torch.bfloat16)
-    w3p = w3[:, _w3_perm_cols(I)].contiguous()
-    xd, w12d, w3d, pgd = x.to(DEV), w12f.to(DEV), w3p.to(DEV), pg.to(DEV)
+    xd, w12d, w3d, pgd = x.to(DEV), w12f.to(DEV), w3.to(DEV), pg.to(DEV)
+    pack = torch.empty(L().ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
+    assert pack.numel() == (I // 32) * 48 * 1024
+    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
     alpha = 8.0 if keel else 1.0
-    _lib.check(L().ttv_mlp_fused(xd.data_ptr(), d, w12d.data_ptr(), w3d.data_ptr(), I, xd.data_ptr(), d,
+    _lib.check(L().ttv_mlp_fused(xd.data_ptr(), d, pack.data_ptr(), I, xd.data_ptr(), d,
                                  pgd.data_ptr() if keel else None, alpha, 1e-5, M, d, _lib.TTV_BF16, S()), "mlp_fused")
     xf = x.double()
     xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
@@ -266,7 +261,7 @@ def test_mlp_fused(M, keel, I):
     y = alpha * xf + h @ w3.double().T
     ref = y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-5) * pg.double() if keel else y
     assert_close(xd.float(), ref, "bf16", scale=1.5)
-    assert L().ttv_mlp_fused(xd.data_ptr(), d, w12d.data_ptr(), w3d.data_ptr(), I, xd.data_ptr(), d, None, 1.0, 1e-5, M, 512,
+    assert L().ttv_mlp_fused(xd.data_ptr(), d, pack.data_ptr(), I, xd.data_ptr(), d, None, 1.0, 1e-5, M, 512,
                              _lib.TTV_BF16, S()) == 3
 
 

@@ -36,7 +36,7 @@ class TowerDims(C.Structure):
 
 class LayerWeights(C.Structure):
     _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
-                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("w3_perm", vp)]
+                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("mlp_pack", vp)]
 
 
 class TowerWeights(C.Structure):
@@ -87,7 +87,9 @@ SYMBOLS = {
                                       C.c_int, C.c_int, vp]),
     "ttv_linear_residual_norm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, f32, vp, f32, vp, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, vp]),
-    "ttv_mlp_fused": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_mlp_pack_bytes": (C.c_int64, [C.c_int]),
+    "ttv_mlp_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ttv_mlp_fused": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                    C.c_int, C.c_int, vp]),
@@ -117,6 +119,7 @@ SYMBOLS = {
     "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ttv_rope_table_build": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "ttv_debug_set": (C.c_int, [C.c_int]),
+    "ttv_debug_stamps": (C.c_int, [vp]),
     "ttv_prof_begin": (C.c_int, [C.c_int, C.c_int]),
     "ttv_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

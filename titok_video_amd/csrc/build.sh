@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libtitok_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vectorize -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
 for f in ttv_elem ttv_gemm ttv_attn ttv_mlp ttv_bwd ttv_train ttv_api; do

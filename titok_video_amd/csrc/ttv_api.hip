@@ -20,6 +20,7 @@ void ttv_set_error(const char* fmt, ...) {
 // ---- measurement hook ----
 int g_ttv_prof_class = 0;
 int g_ttv_debug = 0;
+long long* g_ttv_stamps = nullptr;   // diagnostics: device buffer for in-kernel clock stamps (ttv_debug_stamps)
 static hipEvent_t* g_prof_start = nullptr;
 static hipEvent_t* g_prof_stop = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
@@ -114,12 +115,11 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
-    // Opt-in (TTV_FUSED_MLP=1): correct and parity-tested, but at one wave per SIMD it is not yet faster than the two
-    // GEMM kernels below; kept off the default path until the 8-wave version lands.
-    static const bool use_fused_mlp = getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '1';
-    if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.w12_pn && lw.w3_perm) {
+    // TTV_FUSED_MLP=0 selects the two-GEMM sequence below (A/B measurements; same results up to bf16 rounding of h)
+    static const bool use_fused_mlp = !(getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '0');
+    if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.mlp_pack) {
       // one kernel: pre-norm + w12 + GEGLU + w3 + residual/KEEL + post-norm, in place on x
-      TTV_TRY(ttvk_mlp_fused(ws.x, dm, lw.w12_pn, lw.w3_perm, d->inner, ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln,
+      TTV_TRY(ttvk_mlp_fused(ws.x, dm, lw.mlp_pack, d->inner, ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln,
                              i == 0 ? 1.f : d->alpha, d->eps, L, s));
       continue;
     }
@@ -224,13 +224,23 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
   return ttvk_gemm(EPI_RESID_NORM, a, (hipStream_t)stream);
 }
 
-int ttv_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
-                  const float* post_gain, float alpha, float eps, int M, int width, int dtype, void* stream) {
+int64_t ttv_mlp_pack_bytes(int inner) { return ttvk_mlp_pack_bytes(inner); }
+
+int ttv_mlp_pack(const void* w12_folded, const void* w3, int inner, int width, int dtype, void* packed, void* stream) {
+  if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
+    ttv_set_error("mlp_pack: only bf16, width 256, inner %% 32 == 0");
+    return TTV_ERR_UNSUPPORTED;
+  }
+  return ttvk_mlp_pack(w12_folded, w3, inner, packed, (hipStream_t)stream);
+}
+
+int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
+                  float eps, int M, int width, int dtype, void* stream) {
   if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
     ttv_set_error("mlp_fused: only bf16, width 256, inner %% 32 == 0");
     return TTV_ERR_UNSUPPORTED;
   }
-  return ttvk_mlp_fused(x, ldx, w12_folded, w3_perm, inner, y, ldy, post_gain, alpha, eps, M, (hipStream_t)stream);
+  return ttvk_mlp_fused(x, ldx, mlp_packed, inner, y, ldy, post_gain, alpha, eps, M, (hipStream_t)stream);
 }
 
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
@@ -329,6 +339,11 @@ int ttv_rope_table_build(const float* base_cos, const float* base_sin, int n_ids
 
 int ttv_debug_set(int flags) {
   g_ttv_debug = flags;
+  return TTV_OK;
+}
+
+int ttv_debug_stamps(void* device_buffer) {
+  g_ttv_stamps = (long long*)device_buffer;
   return TTV_OK;
 }
 

@@ -117,9 +117,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         if (sizeof(T) == 2) {
-          const f32x2 lo = geglu_pair_fast((f32x2){acc2[i][j][0], acc2[i][j][1]}, (f32x2){acc[i][j][0], acc[i][j][1]});
-          const f32x2 hi = geglu_pair_fast((f32x2){acc2[i][j][2], acc2[i][j][3]}, (f32x2){acc[i][j][2], acc[i][j][3]});
-          acc[i][j] = (f32x4){lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = geglu_fast(acc2[i][j][e], acc[i][j][e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i][j][e] = gelu_erf(acc2[i][j][e]) * acc[i][j][e];

@@ -5,247 +5,347 @@
 //     y     = alpha * x + h W3^T
 //     x_new = KEEL ? RMSNorm(y) * post_gain : y
 //
-// Why one kernel: unfused, this sub-layer moves x (19 MB) -> h (52 MB write + 52 MB read) -> y fp32 (38 MB write + read)
-// -> x at the benchmark shape; fused it reads x once and writes x_new once (38 MB) and h never leaves the CU.
+// Why one kernel: unfused, this sub-layer moves x (19 MB) -> h (52 MB write + 52 MB read) -> x at the benchmark shape and
+// pays two launches; fused it reads x once, writes x_new once (38 MB) and h never leaves the CU.
 //
-// Structure (bf16, K = d = 256, I % 32 == 0):
-//   * a wave owns NT*16 tokens: their x rows stay in registers as MFMA B fragments for the whole kernel
-//     (NT x 8 k-steps x 16 B), the pre-norm is folded (gain pre-multiplied into W12's columns on the host, rstd from the
-//     register-resident row), and the wave accumulates ALL 256 output features of its tokens (16 m-tiles x NT), so the
-//     KEEL RMSNorm is wave-local (in-lane squares + two xor shuffles).
-//   * the hidden dimension is walked in panels of 32 (x, gate) pairs: a 64-row W12 panel (32 KiB) and the matching
-//     256 x 32 W3 panel (16 KiB) stream L2 -> registers -> double-buffered LDS, shared by the block's 4 waves.
-//   * phase 1: 4 m-tiles (x0, x1, g0, g1) x NT x 8 k-steps MFMAs -> GEGLU in registers.  With mfma_16x16x32's C layout a lane
-//     then holds, for its token, pairs {4kq..4kq+3} and {16+4kq..16+4kq+3}: exactly 8 values = one B fragment of the
-//     second product, provided the k order of that product is  k(kq, j) = j<4 ? 4kq+j : 16+4kq+(j-4).  W3's columns are
-//     stored in that order on the host (weights.py), so phase 2 needs NO cross-lane movement and no LDS round trip.
-//   * phase 2: 16 m-tiles x NT MFMAs (one 32-deep k-step) accumulate y^T.
+// Structure (bf16, K = d = 256, I % 32 == 0): see k_mlp256 below.
+//   * the pre-norm is folded (gain pre-multiplied into W12's columns on the host, rstd from the register-resident row).
+//   * the hidden dimension is walked in panels of 32 (x, gate) pairs.  Per panel the host-packed image (ttv_mlp_pack:
+//     a 64-row W12 panel already XOR-swizzled, 32 KiB, + the matching 256 x 32 W3 slice chunk-major, 16 KiB) is copied
+//     L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB contiguous per wave-instruction), double-buffered.
+//   * GEGLU in registers: with mfma_16x16x32's C layout a lane holds, for its token, features {4kq..4kq+3} of m-tile 0
+//     and {16+4kq..16+4kq+3} of m-tile 1: exactly 8 values = one B fragment of the second product, provided the k order
+//     of that product is  k(kq, j) = j<4 ? 4kq+j : 16+4kq+(j-4).  The W3 slice is packed in that order, so the hidden
+//     tile goes producer lane -> LDS -> the same lane of the consumer wave as one 16-byte vector, no shuffles.
 //   * epilogue: residual reload (L2-hot), alpha*x + acc, row statistics, gain, lane-pair exchange, 16-byte stores.
 #include "ttv_common.h"
 #include "ttv_kernels.h"
 
+#define MLP_W12_CHUNKS 2048   // uint4 per W12 panel image (64 rows x 32 chunks)
+#define MLP_W3_CHUNKS 1024    // uint4 per W3 slice image (4 k-chunks x 256 rows)
+#define MLP_PANEL_CHUNKS (MLP_W12_CHUNKS + MLP_W3_CHUNKS)
+
 struct MlpDev {
   const bf16_t* x; int ldx;
-  const bf16_t* w12;   // [2I, 256], pre-norm gain folded into the columns
-  const bf16_t* w3p;   // [256, I], columns permuted per 32-pair panel (see above)
+  const uint4* pack;   // [I/32][MLP_PANEL_CHUNKS] panel images (ttv_mlp_pack)
   int I;
   bf16_t* y; int ldy;
   const float* post_gain;
   float alpha, eps;
   int M, n_tiles, debug;
+  long long* stamps;   // diagnostics (ttv_debug_stamps): [2 roles][64] s_memtime values of block 0
 };
 
-template <int NT, bool KEEL>
-__global__ __launch_bounds__(256, 1) void k_mlp256(MlpDev p) {
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  uint4* l12 = smem;                  // [2][64 rows * 32 chunks]   W12 panel, XOR-swizzled chunks
-  uint4* l3 = smem + 2 * 64 * 32;     // [2][4 chunks][256 rows]    W3 panel, chunk-major (conflict-free b128 reads)
+// ---- weight packing: builds the per-panel LDS images once per weight version -------------------------------------
+__global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __restrict__ w3, int I, uint4* __restrict__ out) {
+  const int np = I / 32;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= np * MLP_PANEL_CHUNKS) return;
+  const int pn = o / MLP_PANEL_CHUNKS, c = o - pn * MLP_PANEL_CHUNKS;
+  if (c < MLP_W12_CHUNKS) {
+    const int r = c >> 5, cp = c & 31;
+    const int ch = (cp & 16) | ((cp & 15) ^ (r & 15));   // LDS chunk cp of row r holds source chunk ch
+    const int srow = r < 32 ? pn * 32 + r : I + pn * 32 + (r - 32);
+    out[o] = *reinterpret_cast<const uint4*>(w12f + (size_t)srow * 256 + ch * 8);
+  } else {
+    const int c3 = c - MLP_W12_CHUNKS, kq = c3 >> 8, row = c3 & 255;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w3[(size_t)row * I + pn * 32 + (j < 4 ? 4 * kq + j : 16 + 4 * kq + (j - 4))];
+    out[o] = __builtin_bit_cast(uint4, v);
+  }
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Wave-specialised block of 8 waves (two per SIMD, 256 VGPRs each, no AGPRs):
+//   waves 0-3 ("P1"): own NT*16 tokens each: x rows register-resident as B fragments (NT x 8 x 16 B), per panel
+//                     4 m-tiles x NT x 8 k-steps MFMAs -> GEGLU in registers -> the 8 hidden values a lane ends up with
+//                     are exactly one B fragment of the second product; written to LDS as one 16-byte vector.
+//   waves 4-7 ("P2"): wave w+4 owns the same tokens as wave w (they share a SIMD): 16 m-tiles x NT accumulators of
+//                     y^T (all 256 output features -> the KEEL RMSNorm is wave-local), per panel 16 x NT MFMAs on the
+//                     fragment P1 produced ONE iteration earlier, then the residual / norm / store epilogue.
+// The two roles split the register demand that no single wave can hold (x rows + y accumulators) and give every SIMD an
+// MFMA stream (P2) to run under the other wave's VALU phase (GEGLU) without any software pipelining.
+// One barrier per panel; weight images arrive by LDS-DMA one iteration ahead of their use.
+template <int NT, bool KEEL>
+__global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  uint4* const l12 = smem;                                 // [2][MLP_W12_CHUNKS]
+  uint4* const l3 = smem + 2 * MLP_W12_CHUNKS;             // [2][MLP_W3_CHUNKS]
+  uint4* const hb = l3 + 2 * MLP_W3_CHUNKS;                // [2][4 waves][NT][64 lanes]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = wave & 3;   // scalar: DMA bases / role branch stay in SGPRs
+  const bool producer = wave < 4;
   const int l15 = lane & 15, kq = lane >> 4;
   const int np = p.I / 32;
 
-  // staging assignments
-  const int srow = tid >> 5, sch = tid & 31;   // W12: rows srow + 8i (i < 8), 16-byte chunk sch
-  uint4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3;
-#define W12ROW(pn_, i_)                                                                                            \
-  ({                                                                                                               \
-    const int row__ = srow + 8 * (i_);                                                                             \
-    const int wr__ = row__ < 32 ? (pn_) * 32 + row__ : p.I + (pn_) * 32 + (row__ - 32);                            \
-    *reinterpret_cast<const uint4*>(p.w12 + (size_t)wr__ * 256 + sch * 8);                                         \
-  })
-#define GLOAD_PANELS(pn_)                                                                                          \
+  // LDS-DMA of one image by all 8 waves: wave w copies KiB blocks w, w+8, ... (64 lanes x 16 B, lane-linear on both
+  // sides).  Written as asm with a SCALAR base + one per-lane byte offset so that no 64-bit per-lane source pointers have
+  // to stay live across the panel loop (the builtin form had them spilled and reloaded behind vmcnt(0) waits).
+  const uint32_t lane16 = lane * 16;
+  const uint32_t lds_l12 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l12;
+  const uint32_t lds_l3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l3;
+#define GLDS16(sbase_, ldsaddr_)                                                                                   \
   do {                                                                                                             \
-    a0 = W12ROW(pn_, 0); a1 = W12ROW(pn_, 1); a2 = W12ROW(pn_, 2); a3 = W12ROW(pn_, 3);                            \
-    a4 = W12ROW(pn_, 4); a5 = W12ROW(pn_, 5); a6 = W12ROW(pn_, 6); a7 = W12ROW(pn_, 7);                            \
-    const bf16_t* w3r__ = p.w3p + (size_t)tid * p.I + (pn_) * 32;                                                  \
-    b0 = *reinterpret_cast<const uint4*>(w3r__); b1 = *reinterpret_cast<const uint4*>(w3r__ + 8);                  \
-    b2 = *reinterpret_cast<const uint4*>(w3r__ + 16); b3 = *reinterpret_cast<const uint4*>(w3r__ + 24);            \
+    unsigned keep__;                                                                                               \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(lane16), "s"(sbase_), "s"(ldsaddr_) : "memory");                             \
   } while (0)
-#define L12IDX(i_) ((srow + 8 * (i_)) * 32 + ((sch & 16) | ((sch & 15) ^ ((srow + 8 * (i_)) & 15))))
-#define LSTORE_PANELS(buf_)                                                                                        \
+#define GLDS_W12(pn_, buf_)                                                                                        \
   do {                                                                                                             \
-    uint4* d12__ = l12 + (buf_) * (64 * 32);                                                                       \
-    d12__[L12IDX(0)] = a0; d12__[L12IDX(1)] = a1; d12__[L12IDX(2)] = a2; d12__[L12IDX(3)] = a3;                    \
-    d12__[L12IDX(4)] = a4; d12__[L12IDX(5)] = a5; d12__[L12IDX(6)] = a6; d12__[L12IDX(7)] = a7;                    \
-    uint4* d3__ = l3 + (buf_) * (4 * 256);                                                                         \
-    d3__[0 * 256 + tid] = b0; d3__[1 * 256 + tid] = b1; d3__[2 * 256 + tid] = b2; d3__[3 * 256 + tid] = b3;        \
+    const uint4* src__ = p.pack + (size_t)(pn_) * MLP_PANEL_CHUNKS + wave * 64;                                    \
+    const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);             \
   } while (0)
+#define GLDS_W3(pn_, buf_)                                                                                         \
+  do {                                                                                                             \
+    const uint4* src__ = p.pack + (size_t)(pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64;                   \
+    const uint32_t dst__ = lds_l3 + ((buf_) * MLP_W3_CHUNKS + wave * 64) * 16;                                     \
+    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);             \
+  } while (0)
+  // A fragment of W12-image row-tile t_ (rows 16 t_ + l15), k-step s8_
+#define LD12(img_, t_, s8_)                                                                                        \
+  __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
 
+  int n_stamp = 0;
+#define STAMP()                                                                                                    \
+  do {                                                                                                             \
+    if (p.stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && n_stamp < 64)                               \
+      p.stamps[(wave >> 2) * 64 + n_stamp++] = (long long)__builtin_readcyclecounter();                            \
+  } while (0)
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    // ---- token rows of this wave: B fragments + folded pre-norm rstd ----
     int tok[NT];
-    bf16x8 bfr[NT][8];
-    float rstd[NT];
+    STAMP();
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      tok[j] = tile * (64 * NT) + wave * (16 * NT) + j * 16 + l15;
-      const int tc = tok[j] < p.M ? tok[j] : p.M - 1;
-      const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 8;
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
-    }
-    GLOAD_PANELS(0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float ss = 0.f;
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = (float)bfr[j][s8][e];
-          ss = fmaf(v, v, ss);
-        }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
-    }
-    __syncthreads();   // previous tile's last panel fully consumed before buffer 0 is overwritten
-    LSTORE_PANELS(0);
-    __syncthreads();
+    for (int j = 0; j < NT; ++j) tok[j] = tile * (64 * NT) + w4 * (16 * NT) + j * 16 + l15;
 
-    f32x4 out[16][NT];
-#pragma unroll
-    for (int m = 0; m < 16; ++m)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) out[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // every wave is done with the previous tile's LDS contents
+    GLDS_W12(0, 0);
 
-    for (int pn = 0; pn < np; ++pn) {
-      const int buf = pn & 1;
-      if (pn + 1 < np && !(p.debug & 2)) GLOAD_PANELS(pn + 1);
-      const uint4* w12l = l12 + buf * (64 * 32);
-      const uint4* w3l = l3 + buf * (4 * 256);
-
-      // ---- phase 1: (x0, x1, g0, g1) m-tiles of this panel ----
-      f32x4 acc1[4][NT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        const int ch = s8 * 4 + kq;
-        bf16x8 a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int arow = i * 16 + l15;
-          a[i] = __builtin_bit_cast(bf16x8, w12l[arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[j][s8], acc1[i][j], 0, 0, 0);
-      }
-      // ---- GEGLU in registers -> B fragments of phase 2 ----
-      bf16x8 hf[NT];
+    if (producer) {
+      // =========================== P1: hidden panel producer ===========================
+      bf16x8 bfr[NT][8];
+      float rstd[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        float hv[8];
+        const int tc = tok[j] < p.M ? tok[j] : p.M - 1;
+        const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 8;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
+      }
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const f32x2 gg = (f32x2){acc1[2 + i][j][e], acc1[2 + i][j][e + 1]} * rstd[j];
-            const f32x2 xx = (f32x2){acc1[i][j][e], acc1[i][j][e + 1]} * rstd[j];
-            const f32x2 h2 = geglu_pair_fast(gg, xx);
-            hv[4 * i + e] = h2.x;
-            hv[4 * i + e + 1] = h2.y;
+      for (int j = 0; j < NT; ++j) {
+        float ss = 0.f;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = (float)bfr[j][s8][e];
+            ss = fmaf(v, v, ss);
           }
-        hf[j] = (bf16x8){(bf16_t)hv[0], (bf16_t)hv[1], (bf16_t)hv[2], (bf16_t)hv[3],
-                         (bf16_t)hv[4], (bf16_t)hv[5], (bf16_t)hv[6], (bf16_t)hv[7]};
-      }
-      // ---- phase 2: y^T += W3panel h^T ----
-      // A fragments are fetched 8 at a time ahead of their MFMAs (one LDS latency per 8 m-tiles, not one per m-tile)
-#pragma unroll
-      for (int mg = 0; mg < 2; ++mg) {
-        bf16x8 a3f[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a3f[m] = __builtin_bit_cast(bf16x8, w3l[kq * 256 + (mg * 8 + m) * 16 + l15]);
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) out[mg * 8 + m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3f[m], hf[j], out[mg * 8 + m][j], 0, 0, 0);
-      }
-      if (pn + 1 < np && !(p.debug & 2)) LSTORE_PANELS(buf ^ 1);
-      __syncthreads();
-    }
-
-    // ---- epilogue: y = alpha*x + acc ; x_new = KEEL ? RMSNorm(y)*gain : y ----
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const bool tv = tok[j] < p.M;
-      const int tc = tv ? tok[j] : p.M - 1;
-      const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
-      f32x4 r[16];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) r[m] = Vec4<bf16_t>::load(rrow + m * 16);
-      float ss = 0.f;
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        out[m][j] += p.alpha * r[m];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ss = fmaf(out[m][j][e], out[m][j][e], ss);
-      }
-      float scale = 1.0f;
-      if (KEEL) {
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
-        scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+        rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
       }
-      const bool odd = kq & 1;
-      bf16_t* yrow = p.y + (size_t)tc * p.ldy;
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      __syncthreads();
+      STAMP();
+
+      for (int it = 0; it <= np; ++it) {
+        if (it + 1 < np && !(p.debug & 2)) GLDS_W12(it + 1, (it + 1) & 1);
+        if (it < np) {
+          if (!(p.debug & 2) || it == 0) GLDS_W3(it, it & 1);
+          const uint4* img = l12 + (it & 1) * MLP_W12_CHUNKS;
+          f32x4 acc1[4][NT];   // [x 0..15, x 16..31, gate 0..15, gate 16..31][token tile]
+          bf16x8 a[2][4];
 #pragma unroll
-      for (int ip = 0; ip < 8; ++ip) {
-        const int i0 = 2 * ip, i1 = 2 * ip + 1;
-        f32x4 y0 = out[i0][j], y1 = out[i1][j];
-        if (KEEL) {
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.post_gain + i0 * 16 + kq * 4);
-          const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.post_gain + i1 * 16 + kq * 4);
+          for (int i = 0; i < 4; ++i) a[0][i] = LD12(img, i, 0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { y0[e] = y0[e] * scale * g0[e]; y1[e] = y1[e] * scale * g1[e]; }
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc1[i][j] = (f32x4){(p.debug & 32) ? (float)it : 0.f, 0.f, 0.f, 0.f};
+          if (!(p.debug & 32))
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            if (s8 + 1 < 8) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) a[(s8 + 1) & 1][i] = LD12(img, i, s8 + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], bfr[j][s8], acc1[i][j], 0, 0, 0);
+            // pin the software pipeline: the 4 fragment reads of k-step s8+1 are issued before the 4*NT MFMAs of k-step s8
+            if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // phase barrier: the consumer waves start their MFMAs only now, i.e. under this wave's GEGLU (VALU) phase
+          // instead of competing with its MFMAs for the matrix pipe
+          __builtin_amdgcn_s_barrier();
+          if (it >= 4 && it < 10) STAMP();    // P1 MFMAs issued
+          // GEGLU in registers -> one B fragment of the second product per token tile
+          uint4* hdst = hb + (((it & 1) * 4 + w4) * NT) * 64 + lane;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            uint32_t hw[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                float h2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                  const float gg = acc1[2 + i][j][e + u] * rstd[j], xx = acc1[i][j][e + u] * rstd[j];
+                  h2[u] = (p.debug & 4) ? gg + xx : geglu_fast(gg, xx);
+                }
+                typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t q = {(bf16_t)h2[0], (bf16_t)h2[1]};
+                hw[2 * i + (e >> 1)] = __builtin_bit_cast(uint32_t, q);
+              }
+            hdst[j * 64] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+          }
+        } else {
+          __builtin_amdgcn_s_barrier();
         }
-        const bf16x4 q0 = {(bf16_t)y0[0], (bf16_t)y0[1], (bf16_t)y0[2], (bf16_t)y0[3]};
-        const bf16x4 q1 = {(bf16_t)y1[0], (bf16_t)y1[1], (bf16_t)y1[2], (bf16_t)y1[3]};
-        const uint2 p0 = __builtin_bit_cast(uint2, q0), p1 = __builtin_bit_cast(uint2, q1);
-        const uint2 send = odd ? p0 : p1;
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 16, 64);
-        recv.y = __shfl_xor(send.y, 16, 64);
-        const uint4 o = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
-        const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
-        if (tv && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = o;
+        if (it >= 4 && it < 10) STAMP();      // work done
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next images is in LDS
+        __syncthreads();
+        if (it >= 4 && it < 10) STAMP();      // barrier passed
       }
+      STAMP();
+    } else {
+      // =========================== P2: output accumulator / epilogue ===========================
+      f32x4 out[16][NT];
+#pragma unroll
+      for (int m = 0; m < 16; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) out[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      STAMP();
+
+      for (int it = 0; it <= np; ++it) {
+        if (it + 1 < np && !(p.debug & 2)) GLDS_W12(it + 1, (it + 1) & 1);
+        if (it < np && (!(p.debug & 2) || it == 0)) GLDS_W3(it, it & 1);
+        __builtin_amdgcn_s_barrier();   // phase barrier (see the producer)
+        if (it >= 1 && !(p.debug & 16)) {
+          const int pn = it - 1;
+          const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
+          const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT) * 64 + lane;
+          bf16x8 hf[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
+          bf16x8 w3f[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w3f[r] = __builtin_bit_cast(bf16x8, w3l[r * 16]);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[m & 3], hf[j], out[m][j], 0, 0, 0);
+            if (m + 4 < 16) w3f[m & 3] = __builtin_bit_cast(bf16x8, w3l[(m + 4) * 16]);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            if (m + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (it >= 4 && it < 10) STAMP();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (it >= 4 && it < 10) STAMP();
+      }
+      STAMP();
+
+      // ---- epilogue: y = alpha*x + acc ; x_new = KEEL ? RMSNorm(y)*gain : y ----
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bool tv = tok[j] < p.M;
+        const int tc = tv ? tok[j] : p.M - 1;
+        const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
+        float ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          out[m][j] += p.alpha * Vec4<bf16_t>::load(rrow + m * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ss = fmaf(out[m][j][e], out[m][j][e], ss);
+        }
+        float scale = 1.0f;
+        if (KEEL) {
+          ss += __shfl_xor(ss, 16, 64);
+          ss += __shfl_xor(ss, 32, 64);
+          scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+        }
+        const bool odd = kq & 1;
+        bf16_t* yrow = p.y + (size_t)tc * p.ldy;
+#pragma unroll
+        for (int ip = 0; ip < 8; ++ip) {
+          const int i0 = 2 * ip, i1 = 2 * ip + 1;
+          f32x4 y0 = out[i0][j], y1 = out[i1][j];
+          if (KEEL) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.post_gain + i0 * 16 + kq * 4);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.post_gain + i1 * 16 + kq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { y0[e] = y0[e] * scale * g0[e]; y1[e] = y1[e] * scale * g1[e]; }
+          }
+          const bf16x4 q0 = {(bf16_t)y0[0], (bf16_t)y0[1], (bf16_t)y0[2], (bf16_t)y0[3]};
+          const bf16x4 q1 = {(bf16_t)y1[0], (bf16_t)y1[1], (bf16_t)y1[2], (bf16_t)y1[3]};
+          const uint2 p0 = __builtin_bit_cast(uint2, q0), p1 = __builtin_bit_cast(uint2, q1);
+          const uint2 send = odd ? p0 : p1;
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 16, 64);
+          recv.y = __shfl_xor(send.y, 16, 64);
+          const uint4 ov = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+          const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
+          if (tv && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = ov;
+        }
+      }
+      STAMP();
     }
   }
-#undef W12ROW
-#undef GLOAD_PANELS
-#undef L12IDX
-#undef LSTORE_PANELS
+#undef STAMP
+#undef GLDS16
+#undef GLDS_W12
+#undef GLDS_W3
+#undef LD12
 }
 
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner) { return dtype == TTV_BF16 && width == 256 && inner % 32 == 0 && inner > 0; }
 
-int ttvk_mlp_fused(const void* x, int ldx, const void* w12_folded, const void* w3_perm, int inner, void* y, int ldy,
-                   const float* post_gain, float alpha, float eps, int M, hipStream_t s) {
+int64_t ttvk_mlp_pack_bytes(int inner) { return inner > 0 && inner % 32 == 0 ? (int64_t)(inner / 32) * MLP_PANEL_CHUNKS * 16 : 0; }
+
+int ttvk_mlp_pack(const void* w12_folded, const void* w3, int inner, void* packed, hipStream_t s) {
+  TTV_CHECK_ARG(w12_folded && w3 && packed, "mlp_pack: null buffer");
+  TTV_CHECK_ARG(inner > 0 && inner % 32 == 0, "mlp_pack: inner %% 32");
+  TTV_CHECK_ARG(((uintptr_t)w12_folded % 16 == 0) && ((uintptr_t)packed % 16 == 0), "mlp_pack: 16-byte alignment");
+  const int total = inner / 32 * MLP_PANEL_CHUNKS;
+  hipLaunchKernelGGL(k_mlp_pack, dim3(ttv_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)w12_folded, (const bf16_t*)w3, inner,
+                     (uint4*)packed);
+  TTV_CHECK_LAUNCH("mlp_pack");
+  return TTV_OK;
+}
+
+int ttvk_mlp_fused(const void* x, int ldx, const void* packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
+                   float eps, int M, hipStream_t s) {
   if (M == 0) return TTV_OK;
-  TTV_CHECK_ARG(x && w12_folded && w3_perm && y, "mlp_fused: null buffer");
+  TTV_CHECK_ARG(x && packed && y, "mlp_fused: null buffer");
   TTV_CHECK_ARG(inner % 32 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "mlp_fused: inner %% 32, leading dims %% 8");
-  TTV_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w12_folded % 16 == 0) && ((uintptr_t)w3_perm % 16 == 0) && ((uintptr_t)y % 16 == 0) && (inner * 2) % 16 == 0, "mlp_fused: 16-byte alignment");
+  TTV_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)y % 16 == 0), "mlp_fused: 16-byte alignment");
   MlpDev d;
-  d.x = (const bf16_t*)x; d.ldx = ldx; d.w12 = (const bf16_t*)w12_folded; d.w3p = (const bf16_t*)w3_perm; d.I = inner;
-  d.y = (bf16_t*)y; d.ldy = ldy; d.post_gain = post_gain; d.alpha = alpha; d.eps = eps; d.M = M; d.debug = g_ttv_debug;
+  d.x = (const bf16_t*)x; d.ldx = ldx; d.pack = (const uint4*)packed; d.I = inner;
+  d.y = (bf16_t*)y; d.ldy = ldy; d.post_gain = post_gain; d.alpha = alpha; d.eps = eps; d.M = M; d.debug = g_ttv_debug; d.stamps = g_ttv_stamps;
   // tokens per wave (NT*16): pick the tile size that needs the fewest full rounds of the 256 CUs, weighted by tile cost
   const int cus = 256;
   const long c2 = (long)ttv_cdiv(ttv_cdiv(M, 128), cus) * 2, c3 = (long)ttv_cdiv(ttv_cdiv(M, 192), cus) * 3;
   const int nt = (c3 < c2 && !(g_ttv_debug & 8)) ? 3 : 2;   // debug bit3 forces the 2-tile variant
   d.n_tiles = ttv_cdiv(M, 64 * nt);
   const int grid = d.n_tiles < cus ? d.n_tiles : cus;
-  const size_t smem = (2 * 64 * 32 + 2 * 4 * 256) * sizeof(uint4);   // 96 KiB
+  const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4);   // 96 KiB + 8 KiB per token tile
   TtvProfScope prof(TTV_KC_GEMM_GEGLU, s);
 #define LAUNCH_MLP(NT_, KEEL_)                                                                                      \
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_mlp256<NT_, KEEL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_>), dim3(grid), dim3(256), smem, s, d);                                  \
+    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_>), dim3(grid), dim3(512), smem, s, d);                                  \
   } while (0)
   if (post_gain) { if (nt == 3) LAUNCH_MLP(3, true); else LAUNCH_MLP(2, true); }
   else { if (nt == 3) LAUNCH_MLP(3, false); else LAUNCH_MLP(2, false); }

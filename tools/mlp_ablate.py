@@ -1,0 +1,29 @@
+import os, sys, torch, ctypes as C
+sys.path.insert(0, os.getcwd())
+from titok_video_amd import _lib
+lib=_lib.lib(); DEV=torch.device("cuda:0"); S=_lib.stream_ptr(DEV)
+L,d,I=36864,256,704
+bf=torch.bfloat16
+x=(torch.randn(L,d,device=DEV)).to(bf); w12=(torch.randn(2*I,d,device=DEV)*d**-0.5).to(bf); w3=(torch.randn(d,I,device=DEV)*I**-0.5).to(bf)
+gain=torch.ones(d,device=DEV); yb=torch.empty(L,d,dtype=bf,device=DEV)
+mp=torch.empty(lib.ttv_mlp_pack_bytes(I),dtype=torch.uint8,device=DEV)
+lib.ttv_mlp_pack(w12.data_ptr(),w3.data_ptr(),I,d,0,mp.data_ptr(),S)
+def t(fn,it=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)*1e3/it
+for dbg in [0,1,2,4,16,32,4|16,4|32,16|32,2|4|16|32, 2|4|16|32|1]:
+    lib.ttv_debug_set(dbg)
+    print(f"debug {dbg:3d}: {t(lambda: lib.ttv_mlp_fused(x.data_ptr(),d,mp.data_ptr(),I,yb.data_ptr(),d,gain.data_ptr(),8.0,1e-5,L,d,0,S)):7.1f} us", flush=True)
+lib.ttv_debug_set(0)
+# in-kernel stamps of block 0 (wave 0 = producer, wave 4 = consumer)
+st=torch.zeros(128,dtype=torch.int64,device=DEV)
+lib.ttv_debug_stamps(st.data_ptr())
+lib.ttv_mlp_fused(x.data_ptr(),d,mp.data_ptr(),I,yb.data_ptr(),d,gain.data_ptr(),8.0,1e-5,L,d,0,S)
+torch.cuda.synchronize(); lib.ttv_debug_stamps(None)
+s=st.cpu().tolist()
+for role,name in ((0,"P1"),(1,"P2")):
+    v=[t for t in s[role*64:role*64+64] if t]
+    print(name, "n=",len(v), "deltas:", [v[i+1]-v[i] for i in range(len(v)-1)])
