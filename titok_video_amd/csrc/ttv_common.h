@@ -102,3 +102,30 @@ __device__ __forceinline__ float geglu_fast(float g, float x) {
   return (g * __builtin_amdgcn_rcpf(1.0f + e)) * x;
 }
 __device__ __forceinline__ f32x2 geglu_pair_fast(f32x2 g, f32x2 x) { return (f32x2){geglu_fast(g.x, x.x), geglu_fast(g.y, x.y)}; }
+
+// Eight independent geglu_fast() evaluations written stage by stage (clamp/polynomial, exp, 1+e, rcp, products) with
+// scheduling fences in between: the compiler otherwise interleaves only two dependency chains, and a lone wave then
+// stalls on the v_exp_f32 / v_rcp_f32 result latency at every step of every chain.
+__device__ __forceinline__ void geglu_fast8(const float (&g)[8], const float (&x)[8], float (&h)[8]) {
+  float a[8], e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float gc = __builtin_amdgcn_fmed3f(g[k], -8.0f, 8.0f);
+    const float g2 = gc * gc;
+    float q = fmaf(g2, 1.014262858e-03f, -1.067757308e-01f);
+    q = fmaf(q, g2, -2.301121361e+00f);
+    a[k] = q * gc;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = __builtin_amdgcn_exp2f(a[k]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = 1.0f + e[k];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = __builtin_amdgcn_rcpf(e[k]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) h[k] = (g[k] * e[k]) * x[k];
+}

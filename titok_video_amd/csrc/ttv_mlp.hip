@@ -56,259 +56,273 @@ __global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __rest
   }
 }
 
-// Wave-specialised block of 8 waves (two per SIMD, 256 VGPRs each, no AGPRs):
-//   waves 0-3 ("P1"): own NT*16 tokens each: x rows register-resident as B fragments (NT x 8 x 16 B), per panel
-//                     4 m-tiles x NT x 8 k-steps MFMAs -> GEGLU in registers -> the 8 hidden values a lane ends up with
-//                     are exactly one B fragment of the second product; written to LDS as one 16-byte vector.
-//   waves 4-7 ("P2"): wave w+4 owns the same tokens as wave w (they share a SIMD): 16 m-tiles x NT accumulators of
-//                     y^T (all 256 output features -> the KEEL RMSNorm is wave-local), per panel 16 x NT MFMAs on the
-//                     fragment P1 produced ONE iteration earlier, then the residual / norm / store epilogue.
-// The two roles split the register demand that no single wave can hold (x rows + y accumulators) and give every SIMD an
-// MFMA stream (P2) to run under the other wave's VALU phase (GEGLU) without any software pipelining.
+// Block of 8 waves (two per SIMD, 256 VGPRs each, no AGPRs).  Waves w and w+4 share a SIMD and a group of NT*16 tokens;
+// neither can hold both the x rows (NT x 8 x 16 B of B fragments) and all y accumulators (16 m-tiles x NT x 4) of the
+// group, so the token tiles are split between them in complementary roles:
+//     "P1" of a tile: x rows register-resident; per panel 4 m-tiles x 8 k-steps MFMAs -> GEGLU in registers -> the 8 hidden
+//                     values a lane ends up with are exactly one B fragment of the second product -> LDS, one 16-byte vector.
+//     "P2" of a tile: the 16 m-tile accumulators of y^T (all 256 features -> the KEEL RMSNorm is wave-local); per panel
+//                     16 MFMAs on the fragment its partner produced ONE iteration earlier; residual / norm / store epilogue.
+//   NT = 3: wave w   = P1 of tiles {0,1} + P2 of tile {2};   wave w+4 = P1 of tile {2} + P2 of tiles {0,1}
+//   NT = 2: wave w   = P1 of tile {0}    + P2 of tile {1};   wave w+4 = P1 of tile {1} + P2 of tile {0}
+// Both waves carry MFMA and VALU (GEGLU) work in different proportions and drift against each other, so the SIMD's matrix
+// pipe runs one wave's MFMAs under the other's GEGLU without software pipelining.  Program order inside an iteration:
+// P1 MFMAs, P2 MFMAs (previous panel), GEGLU - the P2 MFMAs cover the latency of the P1 results the GEGLU needs.
 // One barrier per panel; weight images arrive by LDS-DMA one iteration ahead of their use.
-template <int NT, bool KEEL>
-__global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  uint4* const l12 = smem;                                 // [2][MLP_W12_CHUNKS]
-  uint4* const l3 = smem + 2 * MLP_W12_CHUNKS;             // [2][MLP_W3_CHUNKS]
-  uint4* const hb = l3 + 2 * MLP_W3_CHUNKS;                // [2][4 waves][NT][64 lanes]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = wave & 3;   // scalar: DMA bases / role branch stay in SGPRs
-  const bool producer = wave < 4;
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int np = p.I / 32;
-
-  // LDS-DMA of one image by all 8 waves: wave w copies KiB blocks w, w+8, ... (64 lanes x 16 B, lane-linear on both
-  // sides).  Written as asm with a SCALAR base + one per-lane byte offset so that no 64-bit per-lane source pointers have
-  // to stay live across the panel loop (the builtin form had them spilled and reloaded behind vmcnt(0) waits).
-  const uint32_t lane16 = lane * 16;
-  const uint32_t lds_l12 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l12;
-  const uint32_t lds_l3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l3;
-#define GLDS16(sbase_, ldsaddr_)                                                                                   \
+#define MLP_LD12(img_, t_, s8_)                                                                                    \
+  __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
+#define MLP_GLDS16(sbase_, ldsaddr_)                                                                               \
   do {                                                                                                             \
     unsigned keep__;                                                                                               \
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
                  : "=&s"(keep__) : "v"(lane16), "s"(sbase_), "s"(ldsaddr_) : "memory");                             \
   } while (0)
+#define MLP_STAMP()                                                                                                \
+  do {                                                                                                             \
+    if (p.stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && n_stamp < 64)                               \
+      p.stamps[(wave >> 2) * 64 + n_stamp++] = (long long)__builtin_readcyclecounter();                            \
+  } while (0)
+
+// One wave's share of one 64*NT-token tile: P1 of token tiles [P1F, P1F+T1), P2 of token tiles [P2F, P2F+NT-T1).
+template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL>
+__device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3, uint4* hb, int tile, int wave, int lane, int& n_stamp) {
+  constexpr int T2 = NT - T1;
+  const int w4 = wave & 3, l15 = lane & 15, kq = lane >> 4;
+  const int np = p.I / 32;
+  // LDS-DMA of one image by all 8 waves: wave w copies KiB blocks w, w+8, ... (64 lanes x 16 B, lane-linear on both
+  // sides); asm with a SCALAR base + one per-lane byte offset: no 64-bit per-lane pointers live across the panel loop
+  const uint32_t lane16 = lane * 16;
+  const uint32_t lds_l12 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l12;
+  const uint32_t lds_l3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l3;
 #define GLDS_W12(pn_, buf_)                                                                                        \
   do {                                                                                                             \
     const uint4* src__ = p.pack + (size_t)(pn_) * MLP_PANEL_CHUNKS + wave * 64;                                    \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);             \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
   } while (0)
 #define GLDS_W3(pn_, buf_)                                                                                         \
   do {                                                                                                             \
     const uint4* src__ = p.pack + (size_t)(pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64;                   \
     const uint32_t dst__ = lds_l3 + ((buf_) * MLP_W3_CHUNKS + wave * 64) * 16;                                     \
-    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);             \
+    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
   } while (0)
-  // A fragment of W12-image row-tile t_ (rows 16 t_ + l15), k-step s8_
-#define LD12(img_, t_, s8_)                                                                                        \
-  __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
 
-  int n_stamp = 0;
-#define STAMP()                                                                                                    \
-  do {                                                                                                             \
-    if (p.stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && n_stamp < 64)                               \
-      p.stamps[(wave >> 2) * 64 + n_stamp++] = (long long)__builtin_readcyclecounter();                            \
-  } while (0)
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    int tok[NT];
-    STAMP();
-#pragma unroll
-    for (int j = 0; j < NT; ++j) tok[j] = tile * (64 * NT) + w4 * (16 * NT) + j * 16 + l15;
+  const int tok0 = tile * (64 * NT) + w4 * (16 * NT) + l15;   // token of tile j: tok0 + 16 j
 
-    __syncthreads();   // every wave is done with the previous tile's LDS contents
-    GLDS_W12(0, 0);
+  MLP_STAMP();
+  __syncthreads();   // every wave is done with the previous tile's LDS contents
+  GLDS_W12(0, 0);
 
-    if (producer) {
-      // =========================== P1: hidden panel producer ===========================
-      bf16x8 bfr[NT][8];
-      float rstd[NT];
+  // ---- P1 tiles: B fragments + folded pre-norm rstd ----
+  bf16x8 bfr[T1][8];
+  float rstd[T1];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int tc = tok[j] < p.M ? tok[j] : p.M - 1;
-        const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 8;
+  for (int j = 0; j < T1; ++j) {
+    const int t = tok0 + 16 * (P1F + j);
+    const int tc = t < p.M ? t : p.M - 1;
+    const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 8;
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
+    for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
+  }
+#pragma unroll
+  for (int j = 0; j < T1; ++j) {
+    float ss = 0.f;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (float)bfr[j][s8][e];
+        ss = fmaf(v, v, ss);
       }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+  }
+  // ---- P2 tiles: y accumulators ----
+  f32x4 out[16][T2];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float ss = 0.f;
+  for (int m = 0; m < 16; ++m)
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = (float)bfr[j][s8][e];
-            ss = fmaf(v, v, ss);
-          }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
-      }
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-      __syncthreads();
-      STAMP();
+    for (int j = 0; j < T2; ++j) out[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-      for (int it = 0; it <= np; ++it) {
-        if (it + 1 < np && !(p.debug & 2)) GLDS_W12(it + 1, (it + 1) & 1);
-        if (it < np) {
-          if (!(p.debug & 2) || it == 0) GLDS_W3(it, it & 1);
-          const uint4* img = l12 + (it & 1) * MLP_W12_CHUNKS;
-          f32x4 acc1[4][NT];   // [x 0..15, x 16..31, gate 0..15, gate 16..31][token tile]
-          bf16x8 a[2][4];
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __syncthreads();
+  MLP_STAMP();
+
+  for (int it = 0; it <= np; ++it) {
+    if (it + 1 < np && !(p.debug & 2)) GLDS_W12(it + 1, (it + 1) & 1);
+    if (it < np && (!(p.debug & 2) || it == 0)) GLDS_W3(it, it & 1);
+
+    f32x4 acc1[4][T1];   // [x 0..15, x 16..31, gate 0..15, gate 16..31][P1 token tile]
+    if (it < np) {
+      // ---- P1 MFMAs of panel `it`: A fragments double-buffered in registers, reads pinned ahead of their MFMAs ----
+      const uint4* img = l12 + (it & 1) * MLP_W12_CHUNKS;
+      bf16x8 a[2][4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) a[0][i] = LD12(img, i, 0);
+      for (int i = 0; i < 4; ++i) a[0][i] = MLP_LD12(img, i, 0);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+      for (int s8 = 0; s8 < 8; ++s8) {
+        if (s8 + 1 < 8) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc1[i][j] = (f32x4){(p.debug & 32) ? (float)it : 0.f, 0.f, 0.f, 0.f};
-          if (!(p.debug & 32))
-#pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) {
-            if (s8 + 1 < 8) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) a[(s8 + 1) & 1][i] = LD12(img, i, s8 + 1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j)
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], bfr[j][s8], acc1[i][j], 0, 0, 0);
-            // pin the software pipeline: the 4 fragment reads of k-step s8+1 are issued before the 4*NT MFMAs of k-step s8
-            if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          // phase barrier: the consumer waves start their MFMAs only now, i.e. under this wave's GEGLU (VALU) phase
-          // instead of competing with its MFMAs for the matrix pipe
-          __builtin_amdgcn_s_barrier();
-          if (it >= 4 && it < 10) STAMP();    // P1 MFMAs issued
-          // GEGLU in registers -> one B fragment of the second product per token tile
-          uint4* hdst = hb + (((it & 1) * 4 + w4) * NT) * 64 + lane;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            uint32_t hw[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int e = 0; e < 4; e += 2) {
-                float h2[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                  const float gg = acc1[2 + i][j][e + u] * rstd[j], xx = acc1[i][j][e + u] * rstd[j];
-                  h2[u] = (p.debug & 4) ? gg + xx : geglu_fast(gg, xx);
-                }
-                typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
-                const bf16x2_t q = {(bf16_t)h2[0], (bf16_t)h2[1]};
-                hw[2 * i + (e >> 1)] = __builtin_bit_cast(uint32_t, q);
-              }
-            hdst[j * 64] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-          }
-        } else {
-          __builtin_amdgcn_s_barrier();
+          for (int i = 0; i < 4; ++i) a[(s8 + 1) & 1][i] = MLP_LD12(img, i, s8 + 1);
         }
-        if (it >= 4 && it < 10) STAMP();      // work done
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next images is in LDS
-        __syncthreads();
-        if (it >= 4 && it < 10) STAMP();      // barrier passed
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < T1; ++j)
+            acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], bfr[j][s8],
+                                                                  s8 ? acc1[i][j] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T1, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      STAMP();
-    } else {
-      // =========================== P2: output accumulator / epilogue ===========================
-      f32x4 out[16][NT];
-#pragma unroll
-      for (int m = 0; m < 16; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) out[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
-      STAMP();
-
-      for (int it = 0; it <= np; ++it) {
-        if (it + 1 < np && !(p.debug & 2)) GLDS_W12(it + 1, (it + 1) & 1);
-        if (it < np && (!(p.debug & 2) || it == 0)) GLDS_W3(it, it & 1);
-        __builtin_amdgcn_s_barrier();   // phase barrier (see the producer)
-        if (it >= 1 && !(p.debug & 16)) {
-          const int pn = it - 1;
-          const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
-          const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT) * 64 + lane;
-          bf16x8 hf[NT];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
-          bf16x8 w3f[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) w3f[r] = __builtin_bit_cast(bf16x8, w3l[r * 16]);
-#pragma unroll
-          for (int m = 0; m < 16; ++m) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[m & 3], hf[j], out[m][j], 0, 0, 0);
-            if (m + 4 < 16) w3f[m & 3] = __builtin_bit_cast(bf16x8, w3l[(m + 4) * 16]);
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-            if (m + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        if (it >= 4 && it < 10) STAMP();
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        if (it >= 4 && it < 10) STAMP();
-      }
-      STAMP();
-
-      // ---- epilogue: y = alpha*x + acc ; x_new = KEEL ? RMSNorm(y)*gain : y ----
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const bool tv = tok[j] < p.M;
-        const int tc = tv ? tok[j] : p.M - 1;
-        const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
-        float ss = 0.f;
-#pragma unroll
+    }
+    // GELU_FIRST swaps the order of the two remaining parts (measured: both waves P2-before-GEGLU is the faster setting -
+    // the P2 MFMAs cover the latency of the P1 results the GEGLU reads)
+    if (!GELU_FIRST) {
+      if (it >= 1 && !(p.debug & 16)) {
+        // ---- P2 MFMAs of panel it-1: y^T += W3slice h^T ----
+        const int pn = it - 1;
+        const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
+        const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT + P2F) * 64 + lane;
+        bf16x8 hf[T2];
+  #pragma unroll
+        for (int j = 0; j < T2; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
+        bf16x8 w3f[4];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) w3f[r] = __builtin_bit_cast(bf16x8, w3l[r * 16]);
+  #pragma unroll
         for (int m = 0; m < 16; ++m) {
-          out[m][j] += p.alpha * Vec4<bf16_t>::load(rrow + m * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ss = fmaf(out[m][j][e], out[m][j][e], ss);
-        }
-        float scale = 1.0f;
-        if (KEEL) {
-          ss += __shfl_xor(ss, 16, 64);
-          ss += __shfl_xor(ss, 32, 64);
-          scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
-        }
-        const bool odd = kq & 1;
-        bf16_t* yrow = p.y + (size_t)tc * p.ldy;
-#pragma unroll
-        for (int ip = 0; ip < 8; ++ip) {
-          const int i0 = 2 * ip, i1 = 2 * ip + 1;
-          f32x4 y0 = out[i0][j], y1 = out[i1][j];
-          if (KEEL) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.post_gain + i0 * 16 + kq * 4);
-            const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.post_gain + i1 * 16 + kq * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { y0[e] = y0[e] * scale * g0[e]; y1[e] = y1[e] * scale * g1[e]; }
-          }
-          const bf16x4 q0 = {(bf16_t)y0[0], (bf16_t)y0[1], (bf16_t)y0[2], (bf16_t)y0[3]};
-          const bf16x4 q1 = {(bf16_t)y1[0], (bf16_t)y1[1], (bf16_t)y1[2], (bf16_t)y1[3]};
-          const uint2 p0 = __builtin_bit_cast(uint2, q0), p1 = __builtin_bit_cast(uint2, q1);
-          const uint2 send = odd ? p0 : p1;
-          uint2 recv;
-          recv.x = __shfl_xor(send.x, 16, 64);
-          recv.y = __shfl_xor(send.y, 16, 64);
-          const uint4 ov = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
-          const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
-          if (tv && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = ov;
+  #pragma unroll
+          for (int j = 0; j < T2; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[m & 3], hf[j], out[m][j], 0, 0, 0);
+          if (m + 4 < 16) w3f[m & 3] = __builtin_bit_cast(bf16x8, w3l[(m + 4) * 16]);
+          __builtin_amdgcn_sched_group_barrier(0x008, T2, 0);
+          if (m + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      STAMP();
+    }
+    if (it < np) {
+      // ---- GEGLU of panel `it` in registers -> one B fragment of the second product per token tile ----
+      uint4* hdst = hb + (((it & 1) * 4 + w4) * NT + P1F) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < T1; ++j) {
+        float gg[8], xx[8], hh[8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            gg[4 * i + e] = acc1[2 + i][j][e] * rstd[j];
+            xx[4 * i + e] = acc1[i][j][e] * rstd[j];
+          }
+        geglu_fast8(gg, xx, hh);
+        uint32_t hw[4];
+        typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bf16x2_t q = {(bf16_t)hh[2 * k], (bf16_t)hh[2 * k + 1]};
+          hw[k] = __builtin_bit_cast(uint32_t, q);
+        }
+        hdst[j * 64] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      }
+    }
+    if (GELU_FIRST) {
+      if (it >= 1 && !(p.debug & 16)) {
+        // ---- P2 MFMAs of panel it-1: y^T += W3slice h^T ----
+        const int pn = it - 1;
+        const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
+        const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT + P2F) * 64 + lane;
+        bf16x8 hf[T2];
+  #pragma unroll
+        for (int j = 0; j < T2; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
+        bf16x8 w3f[4];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) w3f[r] = __builtin_bit_cast(bf16x8, w3l[r * 16]);
+  #pragma unroll
+        for (int m = 0; m < 16; ++m) {
+  #pragma unroll
+          for (int j = 0; j < T2; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[m & 3], hf[j], out[m][j], 0, 0, 0);
+          if (m + 4 < 16) w3f[m & 3] = __builtin_bit_cast(bf16x8, w3l[(m + 4) * 16]);
+          __builtin_amdgcn_sched_group_barrier(0x008, T2, 0);
+          if (m + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (it >= 4 && it < 8) MLP_STAMP();     // work done
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next images is in LDS
+    __syncthreads();
+    if (it >= 4 && it < 8) MLP_STAMP();     // barrier passed
+  }
+  MLP_STAMP();
+
+  // ---- epilogue of the P2 tiles: y = alpha*x + acc ; x_new = KEEL ? RMSNorm(y)*gain : y ----
+#pragma unroll
+  for (int j = 0; j < T2; ++j) {
+    const int t = tok0 + 16 * (P2F + j);
+    const bool tv = t < p.M;
+    const int tc = tv ? t : p.M - 1;
+    const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
+    float ss = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      out[m][j] += p.alpha * Vec4<bf16_t>::load(rrow + m * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss = fmaf(out[m][j][e], out[m][j][e], ss);
+    }
+    float scale = 1.0f;
+    if (KEEL) {
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+    }
+    const bool odd = kq & 1;
+    bf16_t* yrow = p.y + (size_t)tc * p.ldy;
+#pragma unroll
+    for (int ip = 0; ip < 8; ++ip) {
+      const int i0 = 2 * ip, i1 = 2 * ip + 1;
+      f32x4 y0 = out[i0][j], y1 = out[i1][j];
+      if (KEEL) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.post_gain + i0 * 16 + kq * 4);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.post_gain + i1 * 16 + kq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = y0[e] * scale * g0[e]; y1[e] = y1[e] * scale * g1[e]; }
+      }
+      const bf16x4 q0 = {(bf16_t)y0[0], (bf16_t)y0[1], (bf16_t)y0[2], (bf16_t)y0[3]};
+      const bf16x4 q1 = {(bf16_t)y1[0], (bf16_t)y1[1], (bf16_t)y1[2], (bf16_t)y1[3]};
+      const uint2 p0 = __builtin_bit_cast(uint2, q0), p1 = __builtin_bit_cast(uint2, q1);
+      const uint2 send = odd ? p0 : p1;
+      uint2 recv;
+      recv.x = __shfl_xor(send.x, 16, 64);
+      recv.y = __shfl_xor(send.y, 16, 64);
+      const uint4 ov = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+      const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
+      if (tv && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = ov;
     }
   }
-#undef STAMP
-#undef GLDS16
+  MLP_STAMP();
 #undef GLDS_W12
 #undef GLDS_W3
-#undef LD12
 }
+
+template <int NT, bool KEEL>
+__global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  uint4* const l12 = smem;                                 // [2][MLP_W12_CHUNKS]
+  uint4* const l3 = smem + 2 * MLP_W12_CHUNKS;             // [2][MLP_W3_CHUNKS]
+  uint4* const hb = l3 + 2 * MLP_W3_CHUNKS;                // [2][4 wave pairs][NT][64 lanes]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: DMA bases / role branch stay in SGPRs
+  constexpr int TA = NT - NT / 2;   // P1 tiles of the first wave of a pair (2 of 3, 1 of 2)
+  int n_stamp = 0;
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL>(p, l12, l3, hb, tile, wave, lane, n_stamp);
+    else mlp_wave<NT, NT - TA, TA, 0, false, KEEL>(p, l12, l3, hb, tile, wave, lane, n_stamp);
+  }
+}
+#undef MLP_LD12
+#undef MLP_GLDS16
+#undef MLP_STAMP
 
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner) { return dtype == TTV_BF16 && width == 256 && inner % 32 == 0 && inner > 0; }
 
