@@ -248,8 +248,8 @@ def test_mlp_fused(M, keel, I):
     w12f = (w12.float() * ng[None, :]).to(torch.bfloat16)
     xd, w12d, w3d, pgd = x.to(DEV), w12f.to(DEV), w3.to(DEV), pg.to(DEV)
     pack = torch.empty(L().ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
-    assert pack.numel() == (I // 32) * 48 * 1024
-    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
+    assert pack.numel() == (I // 32) * 48 * 1024 + 128 * 1024
+    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), None, I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
     alpha = 8.0 if keel else 1.0
     _lib.check(L().ttv_mlp_fused(xd.data_ptr(), d, pack.data_ptr(), I, xd.data_ptr(), d,
                                  pgd.data_ptr() if keel else None, alpha, 1e-5, M, d, _lib.TTV_BF16, S()), "mlp_fused")
@@ -263,6 +263,38 @@ def test_mlp_fused(M, keel, I):
     assert_close(xd.float(), ref, "bf16", scale=1.5)
     assert L().ttv_mlp_fused(xd.data_ptr(), d, pack.data_ptr(), I, xd.data_ptr(), d, None, 1.0, 1e-5, M, 512,
                              _lib.TTV_BF16, S()) == 3
+
+
+@pytest.mark.parametrize("M", [1, 100, 192, 1000, 40000])
+@pytest.mark.parametrize("keel", [True, False])
+def test_layer_tail_fused(M, keel):
+    """out_proj + residual/KEEL + GEGLU sub-layer + residual/KEEL in one kernel vs the op-by-op definition
+    (transformer.py:104,129-130 / 141-145, 47-56)."""
+    d, I = 256, 704
+    g = torch.Generator().manual_seed(M + 7)
+    x = (torch.randn(M, d, generator=g) * 1.3).to(torch.bfloat16)
+    ao = (torch.randn(M, d, generator=g)).to(torch.bfloat16)
+    wo = (torch.randn(d, d, generator=g) * d ** -0.5).to(torch.bfloat16)
+    w12 = (torch.randn(2 * I, d, generator=g) * d ** -0.5).to(torch.bfloat16)
+    w3 = (torch.randn(d, I, generator=g) * I ** -0.5).to(torch.bfloat16)
+    ng, ag, pg = (1 + 0.1 * torch.randn(d, generator=g) for _ in range(3))
+    w12f = (w12.float() * ng[None, :]).to(torch.bfloat16)
+    xd, aod, w12d, w3d, wod, agd, pgd = (t.to(DEV) for t in (x, ao, w12f, w3, wo, ag, pg))
+    pack = torch.empty(L().ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
+    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), wod.data_ptr(), I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
+    alpha = 8.0 if keel else 1.0
+    _lib.check(L().ttv_layer_tail_fused(aod.data_ptr(), d, agd.data_ptr() if keel else None, alpha, xd.data_ptr(), d, pack.data_ptr(), I,
+                                        xd.data_ptr(), d, pgd.data_ptr() if keel else None, alpha, 1e-5, M, d, _lib.TTV_BF16, S()),
+               "layer_tail_fused")
+    y1 = alpha * x.double() + ao.double() @ wo.double().T
+    x1 = y1 * torch.rsqrt(y1.pow(2).mean(-1, keepdim=True) + 1e-5) * ag.double() if keel else y1
+    x1 = x1.to(torch.bfloat16).double()                                      # the kernel rounds x1 to bf16 (residual stream dtype)
+    xn = x1 * torch.rsqrt(x1.pow(2).mean(-1, keepdim=True) + 1e-5)
+    a, gate = (xn @ w12f.double().T).chunk(2, -1)
+    h = (torch.nn.functional.gelu(gate) * a).to(torch.bfloat16).double()
+    y = alpha * x1 + h @ w3.double().T
+    ref = y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-5) * pg.double() if keel else y
+    assert_close(xd.float(), ref, "bf16", scale=2.0)
 
 
 # ---------------------------------------------------------------------------------------------- attention

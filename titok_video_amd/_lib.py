@@ -88,7 +88,9 @@ SYMBOLS = {
     "ttv_linear_residual_norm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, f32, vp, f32, vp, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, vp]),
     "ttv_mlp_pack_bytes": (C.c_int64, [C.c_int]),
-    "ttv_mlp_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ttv_mlp_pack": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ttv_layer_tail_fused": (C.c_int, [vp, C.c_int, vp, f32, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int,
+                                       C.c_int, vp]),
     "ttv_mlp_fused": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,

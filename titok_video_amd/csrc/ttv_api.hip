@@ -98,6 +98,15 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
     TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim, 1, dt, s));
+    // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h)
+    static const bool use_fused_mlp = !(getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '0');
+    if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.mlp_pack) {
+      // one kernel for the rest of the layer: out_proj + residual/KEEL norm, then pre-norm + w12 + GEGLU + w3 +
+      // residual/KEEL norm, in place on x
+      TTV_TRY(ttvk_mlp_fused(ws.ao, dm, i == 0 ? nullptr : lw.attn_post_ln, i == 0 ? 1.f : d->alpha, ws.x, dm, lw.mlp_pack, d->inner,
+                             ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln, i == 0 ? 1.f : d->alpha, d->eps, L, s));
+      continue;
+    }
     GemmArgs o = {};
     o.dtype = dt;
     o.x = ws.ao; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
@@ -115,14 +124,6 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
-    // TTV_FUSED_MLP=0 selects the two-GEMM sequence below (A/B measurements; same results up to bf16 rounding of h)
-    static const bool use_fused_mlp = !(getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '0');
-    if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.mlp_pack) {
-      // one kernel: pre-norm + w12 + GEGLU + w3 + residual/KEEL + post-norm, in place on x
-      TTV_TRY(ttvk_mlp_fused(ws.x, dm, lw.mlp_pack, d->inner, ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln,
-                             i == 0 ? 1.f : d->alpha, d->eps, L, s));
-      continue;
-    }
     const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
     if (!fold_ffd) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
@@ -226,12 +227,12 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
 
 int64_t ttv_mlp_pack_bytes(int inner) { return ttvk_mlp_pack_bytes(inner); }
 
-int ttv_mlp_pack(const void* w12_folded, const void* w3, int inner, int width, int dtype, void* packed, void* stream) {
+int ttv_mlp_pack(const void* w12_folded, const void* w3, const void* out_proj, int inner, int width, int dtype, void* packed, void* stream) {
   if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
     ttv_set_error("mlp_pack: only bf16, width 256, inner %% 32 == 0");
     return TTV_ERR_UNSUPPORTED;
   }
-  return ttvk_mlp_pack(w12_folded, w3, inner, packed, (hipStream_t)stream);
+  return ttvk_mlp_pack(w12_folded, w3, out_proj, inner, packed, (hipStream_t)stream);
 }
 
 int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
@@ -240,7 +241,19 @@ int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, voi
     ttv_set_error("mlp_fused: only bf16, width 256, inner %% 32 == 0");
     return TTV_ERR_UNSUPPORTED;
   }
-  return ttvk_mlp_fused(x, ldx, mlp_packed, inner, y, ldy, post_gain, alpha, eps, M, (hipStream_t)stream);
+  return ttvk_mlp_fused(nullptr, 0, nullptr, 1.f, x, ldx, mlp_packed, inner, y, ldy, post_gain, alpha, eps, M, (hipStream_t)stream);
+}
+
+int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, float attn_alpha, const void* x, int ldx,
+                         const void* mlp_packed, int inner, void* y, int ldy, const float* ffd_post_gain, float ffd_alpha, float eps,
+                         int M, int width, int dtype, void* stream) {
+  if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
+    ttv_set_error("layer_tail_fused: only bf16, width 256, inner %% 32 == 0");
+    return TTV_ERR_UNSUPPORTED;
+  }
+  TTV_CHECK_ARG(ao, "layer_tail_fused: null attention output");
+  return ttvk_mlp_fused(ao, ldao, attn_post_gain, attn_alpha, x, ldx, mlp_packed, inner, y, ldy, ffd_post_gain, ffd_alpha, eps, M,
+                        (hipStream_t)stream);
 }
 
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,

@@ -62,9 +62,9 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
 // ---- ttv_mlp.hip ----
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner);
 int64_t ttvk_mlp_pack_bytes(int inner);
-int ttvk_mlp_pack(const void* w12_folded, const void* w3, int inner, void* packed, hipStream_t s);
-int ttvk_mlp_fused(const void* x, int ldx, const void* packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
-                   float eps, int M, hipStream_t s);
+int ttvk_mlp_pack(const void* w12_folded, const void* w3, const void* wo, int inner, void* packed, hipStream_t s);
+int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float front_alpha, const void* x, int ldx, const void* packed,
+                   int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, hipStream_t s);
 
 // ---- ttv_bwd.hip (backward kernels) ----
 int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void* dy, int dy_dt, int lddy, const int* dyr,

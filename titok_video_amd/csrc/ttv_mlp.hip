@@ -24,10 +24,15 @@
 #define MLP_W12_CHUNKS 2048   // uint4 per W12 panel image (64 rows x 32 chunks)
 #define MLP_W3_CHUNKS 1024    // uint4 per W3 slice image (4 k-chunks x 256 rows)
 #define MLP_PANEL_CHUNKS (MLP_W12_CHUNKS + MLP_W3_CHUNKS)
+#define MLP_WO_CHUNKS (4 * MLP_W12_CHUNKS)   // out_proj: 4 panel images of 64 rows, appended after the I/32 feed-forward panels
 
 struct MlpDev {
   const bf16_t* x; int ldx;
-  const uint4* pack;   // [I/32][MLP_PANEL_CHUNKS] panel images (ttv_mlp_pack)
+  const uint4* pack;   // [I/32][MLP_PANEL_CHUNKS] panel images, then [4][MLP_W12_CHUNKS] out_proj images (ttv_mlp_pack)
+  // optional fused front (attention out_proj + residual/KEEL, transformer.py:104,141-142): x <- [RMSNorm](fa*x + ao Wo^T)[*fg]
+  const bf16_t* ao; int ldao;
+  const float* front_gain;
+  float front_alpha;
   int I;
   bf16_t* y; int ldy;
   const float* post_gain;
@@ -37,16 +42,29 @@ struct MlpDev {
 };
 
 // ---- weight packing: builds the per-panel LDS images once per weight version -------------------------------------
-__global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __restrict__ w3, int I, uint4* __restrict__ out) {
+__global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __restrict__ w3, const bf16_t* __restrict__ wo, int I,
+                           uint4* __restrict__ out) {
   const int np = I / 32;
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= np * MLP_PANEL_CHUNKS) return;
+  if (o >= np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS) return;
+  if (o >= np * MLP_PANEL_CHUNKS) {
+    // out_proj images: 4 panels of 64 rows, natural k order, same XOR swizzle
+    const int c = o - np * MLP_PANEL_CHUNKS, wp = c / MLP_W12_CHUNKS, cc = c - wp * MLP_W12_CHUNKS;
+    const int r = cc >> 5, cp = cc & 31;
+    const int ch = (cp & 16) | ((cp & 15) ^ (r & 15));
+    out[o] = wo ? *reinterpret_cast<const uint4*>(wo + (size_t)(wp * 64 + r) * 256 + ch * 8) : make_uint4(0, 0, 0, 0);
+    return;
+  }
   const int pn = o / MLP_PANEL_CHUNKS, c = o - pn * MLP_PANEL_CHUNKS;
   if (c < MLP_W12_CHUNKS) {
     const int r = c >> 5, cp = c & 31;
-    const int ch = (cp & 16) | ((cp & 15) ^ (r & 15));   // LDS chunk cp of row r holds source chunk ch
+    const int ch = (cp & 16) | ((cp & 15) ^ (r & 15));   // LDS chunk cp of row r holds source chunk ch = 4 s8 + kq
     const int srow = r < 32 ? pn * 32 + r : I + pn * 32 + (r - 32);
-    out[o] = *reinterpret_cast<const uint4*>(w12f + (size_t)srow * 256 + ch * 8);
+    // k order inside every 32-column step follows the B fragments the kernel builds from C-layout registers:
+    // lane group kq holds columns {4kq..4kq+3} and {16+4kq..16+4kq+3} of the step
+    const bf16_t* src = w12f + (size_t)srow * 256 + (ch >> 2) * 32 + (ch & 3) * 4;
+    const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+    out[o] = make_uint4(lo.x, lo.y, hi.x, hi.y);
   } else {
     const int c3 = c - MLP_W12_CHUNKS, kq = c3 >> 8, row = c3 & 255;
     bf16x8 v;
@@ -71,11 +89,12 @@ __global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __rest
 // One barrier per panel; weight images arrive by LDS-DMA one iteration ahead of their use.
 #define MLP_LD12(img_, t_, s8_)                                                                                    \
   __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
-#define MLP_GLDS16(sbase_, ldsaddr_)                                                                               \
+#define MLP_GLDS16(chunk_, ldsaddr_)   /* copies 64 uint4 starting at p.pack[chunk_] (wave-uniform) to LDS byte address ldsaddr_ */ \
   do {                                                                                                             \
     unsigned keep__;                                                                                               \
+    const uint32_t voff__ = lane16 + (uint32_t)(chunk_) * 16u;                                                     \
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep__) : "v"(lane16), "s"(sbase_), "s"(ldsaddr_) : "memory");                             \
+                 : "=&s"(keep__) : "v"(voff__), "s"(p.pack), "s"(ldsaddr_) : "memory");                             \
   } while (0)
 #define MLP_STAMP()                                                                                                \
   do {                                                                                                             \
@@ -84,8 +103,9 @@ __global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __rest
   } while (0)
 
 // One wave's share of one 64*NT-token tile: P1 of token tiles [P1F, P1F+T1), P2 of token tiles [P2F, P2F+NT-T1).
-template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL>
-__device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3, uint4* hb, int tile, int wave, int lane, int& n_stamp) {
+template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL, bool FRONT>
+__device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3, uint4* hb, const float* gl, int tile, int wave, int lane,
+                                         int& n_stamp) {
   constexpr int T2 = NT - T1;
   const int w4 = wave & 3, l15 = lane & 15, kq = lane >> 4;
   const int np = p.I / 32;
@@ -96,13 +116,13 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   const uint32_t lds_l3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l3;
 #define GLDS_W12(pn_, buf_)                                                                                        \
   do {                                                                                                             \
-    const uint4* src__ = p.pack + (size_t)(pn_) * MLP_PANEL_CHUNKS + wave * 64;                                    \
+    const int src__ = (pn_) * MLP_PANEL_CHUNKS + wave * 64;                                                        \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
     _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
   } while (0)
 #define GLDS_W3(pn_, buf_)                                                                                         \
   do {                                                                                                             \
-    const uint4* src__ = p.pack + (size_t)(pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64;                   \
+    const int src__ = (pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64;                                       \
     const uint32_t dst__ = lds_l3 + ((buf_) * MLP_W3_CHUNKS + wave * 64) * 16;                                     \
     _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
   } while (0)
@@ -111,32 +131,136 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
 
   MLP_STAMP();
   __syncthreads();   // every wave is done with the previous tile's LDS contents
-  GLDS_W12(0, 0);
 
-  // ---- P1 tiles: B fragments + folded pre-norm rstd ----
-  bf16x8 bfr[T1][8];
+  bf16x8 bfr[T1][8];   // x rows of the P1 tiles as B fragments, k order per 32-step: {4kq..+3, 16+4kq..+3}
   float rstd[T1];
+  if (FRONT) {
+    // ---- fused front: x' = [RMSNorm](fa*x + ao Wo^T)[*fg] for the P1 tiles (the wave then owns all 256 features of its
+    // tokens in C layout, which IS the B-fragment layout above); Wo streams through the W12 buffers as 4 panel images ----
+#define GLDS_WO(wp_, buf_)                                                                                         \
+  do {                                                                                                             \
+    const int src__ = np * MLP_PANEL_CHUNKS + (wp_) * MLP_W12_CHUNKS + wave * 64;                                  \
+    const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
+  } while (0)
+    GLDS_WO(0, 0);
+    bf16x8 abf[T1][8];
 #pragma unroll
-  for (int j = 0; j < T1; ++j) {
-    const int t = tok0 + 16 * (P1F + j);
-    const int tc = t < p.M ? t : p.M - 1;
-    const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 8;
+    for (int j = 0; j < T1; ++j) {
+      const int t = tok0 + 16 * (P1F + j);
+      const int tc = t < p.M ? t : p.M - 1;
+      const bf16_t* ar = p.ao + (size_t)tc * p.ldao + kq * 8;
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
-  }
+      for (int s8 = 0; s8 < 8; ++s8) abf[j][s8] = *reinterpret_cast<const bf16x8*>(ar + s8 * 32);
+    }
+    f32x4 facc[16][T1];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < T1; ++j) {
-    float ss = 0.f;
+    for (int wp = 0; wp < 4; ++wp) {
+      if (wp + 1 < 4) GLDS_WO(wp + 1, (wp + 1) & 1);
+      const uint4* img = l12 + (wp & 1) * MLP_W12_CHUNKS;
+      bf16x8 a[2][4];
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8)
+      for (int i = 0; i < 4; ++i) a[0][i] = MLP_LD12(img, i, 0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = (float)bfr[j][s8][e];
-        ss = fmaf(v, v, ss);
+      for (int s8 = 0; s8 < 8; ++s8) {
+        if (s8 + 1 < 8) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[(s8 + 1) & 1][i] = MLP_LD12(img, i, s8 + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < T1; ++j)
+            facc[4 * wp + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], abf[j][s8],
+                                                                           s8 ? facc[4 * wp + i][j] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T1, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+#undef GLDS_WO
+    GLDS_W12(0, 0);
+    // residual, row statistics, gain; the bf16-rounded x' goes to y (residual of the P2 owner's epilogue) and, as is,
+    // into the B fragments of phase 1
+#pragma unroll
+    for (int j = 0; j < T1; ++j) {
+      const int t = tok0 + 16 * (P1F + j);
+      const bool tv = t < p.M;
+      const int tc = tv ? t : p.M - 1;
+      const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
+      float ss = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        facc[m][j] += p.front_alpha * Vec4<bf16_t>::load(rrow + m * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = fmaf(facc[m][j][e], facc[m][j][e], ss);
+      }
+      float scale = 1.0f;
+      if (p.front_gain) {
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+      }
+      bf16_t* yrow = p.y + (size_t)tc * p.ldy + kq * 4;
+      float ss2 = 0.f;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        bf16x4 q[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int m = 2 * s8 + u;
+          f32x4 v = facc[m][j];
+          if (p.front_gain) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gl + 256 + m * 16 + kq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * scale * g[e];
+          }
+          q[u] = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float r = (float)q[u][e];
+            ss2 = fmaf(r, r, ss2);
+          }
+          if (tv) *reinterpret_cast<uint2*>(yrow + m * 16) = __builtin_bit_cast(uint2, q[u]);
+        }
+        bfr[j][s8] = (bf16x8){q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3]};
+      }
+      ss2 += __shfl_xor(ss2, 16, 64);
+      ss2 += __shfl_xor(ss2, 32, 64);
+      rstd[j] = 1.0f / sqrtf(ss2 * (1.0f / 256.0f) + p.eps);
+    }
+  } else {
+    GLDS_W12(0, 0);
+    // ---- P1 tiles: B fragments + folded pre-norm rstd ----
+#pragma unroll
+    for (int j = 0; j < T1; ++j) {
+      const int t = tok0 + 16 * (P1F + j);
+      const int tc = t < p.M ? t : p.M - 1;
+      const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 4;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(xr + s8 * 32), hi = *reinterpret_cast<const uint2*>(xr + s8 * 32 + 16);
+        bfr[j][s8] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < T1; ++j) {
+      float ss = 0.f;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (float)bfr[j][s8][e];
+          ss = fmaf(v, v, ss);
+        }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+    }
   }
   // ---- P2 tiles: y accumulators ----
   f32x4 out[16][T2];
@@ -262,11 +386,21 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     const int t = tok0 + 16 * (P2F + j);
     const bool tv = t < p.M;
     const int tc = tv ? t : p.M - 1;
-    const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
+    // FRONT: the residual is the x' its partner wave stored to y during the prologue - read at agent scope (L2), not
+    // through this CU's L1
+    const bf16_t* rrow = FRONT ? p.y + (size_t)tc * p.ldy + kq * 4 : p.x + (size_t)tc * p.ldx + kq * 4;
     float ss = 0.f;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-      out[m][j] += p.alpha * Vec4<bf16_t>::load(rrow + m * 16);
+      f32x4 rv;
+      if (FRONT) {
+        const uint64_t raw = __hip_atomic_load(reinterpret_cast<const uint64_t*>(rrow + m * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
+        rv = (f32x4){(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+      } else {
+        rv = Vec4<bf16_t>::load(rrow + m * 16);
+      }
+      out[m][j] += p.alpha * rv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ss = fmaf(out[m][j][e], out[m][j][e], ss);
     }
@@ -283,8 +417,8 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       f32x4 y0 = out[i0][j], y1 = out[i1][j];
       if (KEEL) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.post_gain + i0 * 16 + kq * 4);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.post_gain + i1 * 16 + kq * 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gl + i0 * 16 + kq * 4);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gl + i1 * 16 + kq * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { y0[e] = y0[e] * scale * g0[e]; y1[e] = y1[e] * scale * g1[e]; }
       }
@@ -305,19 +439,25 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
 #undef GLDS_W3
 }
 
-template <int NT, bool KEEL>
+template <int NT, bool KEEL, bool FRONT>
 __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* const l12 = smem;                                 // [2][MLP_W12_CHUNKS]
   uint4* const l3 = smem + 2 * MLP_W12_CHUNKS;             // [2][MLP_W3_CHUNKS]
   uint4* const hb = l3 + 2 * MLP_W3_CHUNKS;                // [2][4 wave pairs][NT][64 lanes]
+  float* const gl = reinterpret_cast<float*>(hb + 2 * 4 * NT * 64);   // [256] post_gain, [256] front_gain (read per m-tile by
+                                                                       // low-latency LDS loads instead of serialised global loads)
+  if (threadIdx.x < 256) {
+    gl[threadIdx.x] = p.post_gain ? p.post_gain[threadIdx.x] : 1.0f;
+    gl[256 + threadIdx.x] = (FRONT && p.front_gain) ? p.front_gain[threadIdx.x] : 1.0f;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: DMA bases / role branch stay in SGPRs
   constexpr int TA = NT - NT / 2;   // P1 tiles of the first wave of a pair (2 of 3, 1 of 2)
   int n_stamp = 0;
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL>(p, l12, l3, hb, tile, wave, lane, n_stamp);
-    else mlp_wave<NT, NT - TA, TA, 0, false, KEEL>(p, l12, l3, hb, tile, wave, lane, n_stamp);
+    if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL, FRONT>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
+    else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
   }
 }
 #undef MLP_LD12
@@ -326,43 +466,49 @@ __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
 
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner) { return dtype == TTV_BF16 && width == 256 && inner % 32 == 0 && inner > 0; }
 
-int64_t ttvk_mlp_pack_bytes(int inner) { return inner > 0 && inner % 32 == 0 ? (int64_t)(inner / 32) * MLP_PANEL_CHUNKS * 16 : 0; }
+int64_t ttvk_mlp_pack_bytes(int inner) {
+  return inner > 0 && inner % 32 == 0 ? ((int64_t)(inner / 32) * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS) * 16 : 0;
+}
 
-int ttvk_mlp_pack(const void* w12_folded, const void* w3, int inner, void* packed, hipStream_t s) {
+int ttvk_mlp_pack(const void* w12_folded, const void* w3, const void* wo, int inner, void* packed, hipStream_t s) {
   TTV_CHECK_ARG(w12_folded && w3 && packed, "mlp_pack: null buffer");
   TTV_CHECK_ARG(inner > 0 && inner % 32 == 0, "mlp_pack: inner %% 32");
-  TTV_CHECK_ARG(((uintptr_t)w12_folded % 16 == 0) && ((uintptr_t)packed % 16 == 0), "mlp_pack: 16-byte alignment");
-  const int total = inner / 32 * MLP_PANEL_CHUNKS;
-  hipLaunchKernelGGL(k_mlp_pack, dim3(ttv_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)w12_folded, (const bf16_t*)w3, inner,
-                     (uint4*)packed);
+  TTV_CHECK_ARG(((uintptr_t)w12_folded % 16 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)wo % 16 == 0), "mlp_pack: 16-byte alignment");
+  const int total = inner / 32 * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS;
+  hipLaunchKernelGGL(k_mlp_pack, dim3(ttv_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)w12_folded, (const bf16_t*)w3,
+                     (const bf16_t*)wo, inner, (uint4*)packed);
   TTV_CHECK_LAUNCH("mlp_pack");
   return TTV_OK;
 }
 
-int ttvk_mlp_fused(const void* x, int ldx, const void* packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
-                   float eps, int M, hipStream_t s) {
+int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float front_alpha, const void* x, int ldx, const void* packed,
+                   int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, hipStream_t s) {
   if (M == 0) return TTV_OK;
   TTV_CHECK_ARG(x && packed && y, "mlp_fused: null buffer");
-  TTV_CHECK_ARG(inner % 32 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "mlp_fused: inner %% 32, leading dims %% 8");
-  TTV_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)y % 16 == 0), "mlp_fused: 16-byte alignment");
+  TTV_CHECK_ARG(inner % 32 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!ao || ldao % 8 == 0), "mlp_fused: inner %% 32, leading dims %% 8");
+  TTV_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)ao % 16 == 0),
+                "mlp_fused: 16-byte alignment");
   MlpDev d;
   d.x = (const bf16_t*)x; d.ldx = ldx; d.pack = (const uint4*)packed; d.I = inner;
+  d.ao = (const bf16_t*)ao; d.ldao = ldao; d.front_gain = front_gain; d.front_alpha = front_alpha;
   d.y = (bf16_t*)y; d.ldy = ldy; d.post_gain = post_gain; d.alpha = alpha; d.eps = eps; d.M = M; d.debug = g_ttv_debug; d.stamps = g_ttv_stamps;
-  // tokens per wave (NT*16): pick the tile size that needs the fewest full rounds of the 256 CUs, weighted by tile cost
+  // tokens per wave pair (NT*16): pick the tile size that needs the fewest full rounds of the 256 CUs, weighted by tile cost
   const int cus = 256;
   const long c2 = (long)ttv_cdiv(ttv_cdiv(M, 128), cus) * 2, c3 = (long)ttv_cdiv(ttv_cdiv(M, 192), cus) * 3;
   const int nt = (c3 < c2 && !(g_ttv_debug & 8)) ? 3 : 2;   // debug bit3 forces the 2-tile variant
   d.n_tiles = ttv_cdiv(M, 64 * nt);
   const int grid = d.n_tiles < cus ? d.n_tiles : cus;
-  const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4);   // 96 KiB + 8 KiB per token tile
+  const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4) + 2048;   // 96 KiB + 8 KiB per token tile + gains
   TtvProfScope prof(TTV_KC_GEMM_GEGLU, s);
-#define LAUNCH_MLP(NT_, KEEL_)                                                                                      \
+#define LAUNCH_MLP(NT_, KEEL_, FRONT_)                                                                              \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)k_mlp256<NT_, KEEL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_>), dim3(grid), dim3(512), smem, s, d);                                  \
+    (void)hipFuncSetAttribute((const void*)k_mlp256<NT_, KEEL_, FRONT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_, FRONT_>), dim3(grid), dim3(512), smem, s, d);                          \
   } while (0)
-  if (post_gain) { if (nt == 3) LAUNCH_MLP(3, true); else LAUNCH_MLP(2, true); }
-  else { if (nt == 3) LAUNCH_MLP(3, false); else LAUNCH_MLP(2, false); }
+#define LAUNCH_MLP_F(NT_, KEEL_) do { if (ao) LAUNCH_MLP(NT_, KEEL_, true); else LAUNCH_MLP(NT_, KEEL_, false); } while (0)
+  if (post_gain) { if (nt == 3) LAUNCH_MLP_F(3, true); else LAUNCH_MLP_F(2, true); }
+  else { if (nt == 3) LAUNCH_MLP_F(3, false); else LAUNCH_MLP_F(2, false); }
+#undef LAUNCH_MLP_F
 #undef LAUNCH_MLP
   TTV_CHECK_LAUNCH("mlp_fused");
   return TTV_OK;

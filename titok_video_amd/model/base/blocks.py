@@ -226,19 +226,20 @@ class _WeightPack:
             keep.append(t)
             return t.data_ptr()
 
-        def mlp_packed(w12, g, w3):
-            """Per-panel LDS images of the fused feed-forward kernel (csrc/ttv_mlp.hip), built on the device by ttv_mlp_pack
-            from w12 * gain[None, :] and w3."""
+        def mlp_packed(w12, g, w3, wo):
+            """Per-panel LDS images of the fused layer-tail kernel (csrc/ttv_mlp.hip), built on the device by ttv_mlp_pack
+            from w12 * gain[None, :], w3 and out_proj."""
             if not fold or w3.shape[1] % 32:
                 return None
             w12f = (w12.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
             w12f = w12f.to(dtype).contiguous()
             w3c = w3.detach().to(device=device, dtype=dtype).contiguous()
+            woc = wo.detach().to(device=device, dtype=dtype).contiguous()
             inner = int(w3.shape[1])
             out = torch.empty(_lib.lib().ttv_mlp_pack_bytes(inner), dtype=torch.uint8, device=device)
-            _lib.check(_lib.lib().ttv_mlp_pack(w12f.data_ptr(), w3c.data_ptr(), inner, tower.width, _lib.TTV_BF16,
+            _lib.check(_lib.lib().ttv_mlp_pack(w12f.data_ptr(), w3c.data_ptr(), woc.data_ptr(), inner, tower.width, _lib.TTV_BF16,
                                                out.data_ptr(), _lib.stream_ptr(device)), "mlp_pack")
-            keep.extend([w12f, w3c, out])    # stream-ordered: inputs stay alive with the pack
+            keep.extend([w12f, w3c, woc, out])    # stream-ordered: inputs stay alive with the pack
             return out.data_ptr()
 
         perm = tower._patch_perm().to(device)
@@ -260,7 +261,7 @@ class _WeightPack:
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
                 ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
                 to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight), w12_pn=folded(f.w12.weight, f.norm.weight),
-                mlp_pack=mlp_packed(f.w12.weight, f.norm.weight, f.w3.weight))
+                mlp_pack=mlp_packed(f.w12.weight, f.norm.weight, f.w3.weight, a.out_proj.weight))
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),

@@ -74,9 +74,11 @@ for dbg in ([0, 1] if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
     timeit("residual+norm fused K256 N256 (rownorm)", lambda: lib.ttv_linear_residual_norm(x.data_ptr(), d, wo.data_ptr(), d, yb.data_ptr(), d, 8.0, gain.data_ptr(), 1e-5, yb.data_ptr(), d, L, d, d, 0, S),
            2.0 * L * d * d, L * d * 6)
     mpack = torch.empty(lib.ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
-    lib.ttv_mlp_pack(w12.data_ptr(), w3.data_ptr(), I, d, 0, mpack.data_ptr(), S)
+    lib.ttv_mlp_pack(w12.data_ptr(), w3.data_ptr(), wo.data_ptr(), I, d, 0, mpack.data_ptr(), S)
     timeit("fused MLP (w12+geglu+w3+keel+norm)", lambda: lib.ttv_mlp_fused(x.data_ptr(), d, mpack.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, S),
            2.0 * L * d * 3 * I, L * d * 4)
+    timeit("layer tail fused (out_proj+keel+mlp+keel)", lambda: lib.ttv_layer_tail_fused(ao.data_ptr(), d, gain.data_ptr(), 8.0, x.data_ptr(), d, mpack.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, S),
+           2.0 * L * d * (3 * I + d), L * d * 6)
     timeit("residual+norm fused K704 N256 (rowtile)", lambda: lib.ttv_linear_residual_norm(h.data_ptr(), I, w3.data_ptr(), I, yb.data_ptr(), d, 8.0, gain.data_ptr(), 1e-5, yb.data_ptr(), d, L, d, I, 0, S),
            2.0 * L * I * d, L * (I * 2 + d * 4))
     if QUICK:

@@ -7,7 +7,7 @@ bf=torch.bfloat16
 x=(torch.randn(L,d,device=DEV)).to(bf); w12=(torch.randn(2*I,d,device=DEV)*d**-0.5).to(bf); w3=(torch.randn(d,I,device=DEV)*I**-0.5).to(bf)
 gain=torch.ones(d,device=DEV); yb=torch.empty(L,d,dtype=bf,device=DEV)
 mp=torch.empty(lib.ttv_mlp_pack_bytes(I),dtype=torch.uint8,device=DEV)
-lib.ttv_mlp_pack(w12.data_ptr(),w3.data_ptr(),I,d,0,mp.data_ptr(),S)
+lib.ttv_mlp_pack(w12.data_ptr(),w3.data_ptr(),None,I,d,0,mp.data_ptr(),S)
 def t(fn,it=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
@@ -26,4 +26,14 @@ torch.cuda.synchronize(); lib.ttv_debug_stamps(None)
 s=st.cpu().tolist()
 for role,name in ((0,"P1"),(1,"P2")):
     v=[t for t in s[role*64:role*64+64] if t]
+    print(name, "n=",len(v), "deltas:", [v[i+1]-v[i] for i in range(len(v)-1)])
+# layer tail (fused front) stamps
+ao=(torch.randn(L,d,device=DEV)).to(bf); wo=(torch.randn(d,d,device=DEV)*d**-0.5).to(bf)
+lib.ttv_mlp_pack(w12.data_ptr(),w3.data_ptr(),wo.data_ptr(),I,d,0,mp.data_ptr(),S)
+tail=lambda: lib.ttv_layer_tail_fused(ao.data_ptr(),d,gain.data_ptr(),8.0,x.data_ptr(),d,mp.data_ptr(),I,yb.data_ptr(),d,gain.data_ptr(),8.0,1e-5,L,d,0,S)
+print(f"layer tail: {t(tail):7.1f} us")
+st.zero_(); lib.ttv_debug_stamps(st.data_ptr()); tail(); torch.cuda.synchronize(); lib.ttv_debug_stamps(None)
+s=st.cpu().tolist()
+for role,name in ((0,"A"),(1,"B")):
+    v=[q for q in s[role*64:role*64+64] if q]
     print(name, "n=",len(v), "deltas:", [v[i+1]-v[i] for i in range(len(v)-1)])
