@@ -87,6 +87,9 @@ __global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __rest
 // pipe runs one wave's MFMAs under the other's GEGLU without software pipelining.  Program order inside an iteration:
 // P1 MFMAs, P2 MFMAs (previous panel), GEGLU - the P2 MFMAs cover the latency of the P1 results the GEGLU needs.
 // One barrier per panel; weight images arrive by LDS-DMA one iteration ahead of their use.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 cvt4(bf16x4 b) { return (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]}; }
 #define MLP_LD12(img_, t_, s8_)                                                                                    \
   __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
 #define MLP_GLDS16(chunk_, ldsaddr_)   /* copies 64 uint4 starting at p.pack[chunk_] (wave-uniform) to LDS byte address ldsaddr_ */ \
@@ -128,6 +131,12 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   } while (0)
 
   const int tok0 = tile * (64 * NT) + w4 * (16 * NT) + l15;   // token of tile j: tok0 + 16 j
+  // explicitly global (address space 1) byte pointers: accesses are then global_* with an SGPR base, never flat_*
+  typedef __attribute__((address_space(1))) char gchar;
+  typedef __attribute__((address_space(1))) const char gcchar;
+  gcchar* const gx = (gcchar*)p.x;
+  gcchar* const gao = (gcchar*)p.ao;
+  gchar* const gy = (gchar*)p.y;
 
   MLP_STAMP();
   __syncthreads();   // every wave is done with the previous tile's LDS contents
@@ -149,9 +158,9 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     for (int j = 0; j < T1; ++j) {
       const int t = tok0 + 16 * (P1F + j);
       const int tc = t < p.M ? t : p.M - 1;
-      const bf16_t* ar = p.ao + (size_t)tc * p.ldao + kq * 8;
+      const uint32_t aoff = ((uint32_t)tc * (uint32_t)p.ldao + kq * 8) * 2u;
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) abf[j][s8] = *reinterpret_cast<const bf16x8*>(ar + s8 * 32);
+      for (int s8 = 0; s8 < 8; ++s8) abf[j][s8] = *(const __attribute__((address_space(1))) bf16x8*)(gao + aoff + s8 * 64);
     }
     f32x4 facc[16][T1];
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -191,11 +200,13 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       const int t = tok0 + 16 * (P1F + j);
       const bool tv = t < p.M;
       const int tc = tv ? t : p.M - 1;
-      const bf16_t* rrow = p.x + (size_t)tc * p.ldx + kq * 4;
+      // scalar base + 32-bit per-lane byte offsets everywhere below: 64-bit row pointers in VGPRs get spilled in this kernel
+      // and every scratch reload comes with a vmcnt(0) that serialises the stores / drains the LDS-DMA in flight
+      const uint32_t roff = ((uint32_t)tc * (uint32_t)p.ldx + kq * 4) * 2u;
       float ss = 0.f;
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        facc[m][j] += p.front_alpha * Vec4<bf16_t>::load(rrow + m * 16);
+        facc[m][j] += p.front_alpha * cvt4(*(const __attribute__((address_space(1))) bf16x4*)(gx + roff + m * 32));
 #pragma unroll
         for (int e = 0; e < 4; ++e) ss = fmaf(facc[m][j][e], facc[m][j][e], ss);
       }
@@ -205,7 +216,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
         ss += __shfl_xor(ss, 32, 64);
         scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
       }
-      bf16_t* yrow = p.y + (size_t)tc * p.ldy + kq * 4;
+      const uint32_t yoff = ((uint32_t)tc * (uint32_t)p.ldy + kq * 4) * 2u;
       float ss2 = 0.f;
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
@@ -225,7 +236,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
             const float r = (float)q[u][e];
             ss2 = fmaf(r, r, ss2);
           }
-          if (tv) *reinterpret_cast<uint2*>(yrow + m * 16) = __builtin_bit_cast(uint2, q[u]);
+          if (tv) *(__attribute__((address_space(1))) u32x2_t*)(gy + yoff + m * 32) = __builtin_bit_cast(u32x2_t, q[u]);
         }
         bfr[j][s8] = (bf16x8){q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3]};
       }
@@ -240,11 +251,12 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     for (int j = 0; j < T1; ++j) {
       const int t = tok0 + 16 * (P1F + j);
       const int tc = t < p.M ? t : p.M - 1;
-      const bf16_t* xr = p.x + (size_t)tc * p.ldx + kq * 4;
+      const uint32_t xoff = ((uint32_t)tc * (uint32_t)p.ldx + kq * 4) * 2u;
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(xr + s8 * 32), hi = *reinterpret_cast<const uint2*>(xr + s8 * 32 + 16);
-        bfr[j][s8] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        const u32x2_t lo = *(const __attribute__((address_space(1))) u32x2_t*)(gx + xoff + s8 * 64);
+        const u32x2_t hi = *(const __attribute__((address_space(1))) u32x2_t*)(gx + xoff + (s8 * 64 + 32));
+        bfr[j][s8] = __builtin_bit_cast(bf16x8, (u32x4_t){lo.x, lo.y, hi.x, hi.y});
       }
     }
 #pragma unroll
@@ -387,18 +399,19 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     const bool tv = t < p.M;
     const int tc = tv ? t : p.M - 1;
     // FRONT: the residual is the x' its partner wave stored to y during the prologue - read at agent scope (L2), not
-    // through this CU's L1
-    const bf16_t* rrow = FRONT ? p.y + (size_t)tc * p.ldy + kq * 4 : p.x + (size_t)tc * p.ldx + kq * 4;
+    // through this CU's L1.  Scalar base + 32-bit byte offsets (see the front).
+    const uint32_t roff = FRONT ? ((uint32_t)tc * (uint32_t)p.ldy + kq * 4) * 2u : ((uint32_t)tc * (uint32_t)p.ldx + kq * 4) * 2u;
     float ss = 0.f;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       f32x4 rv;
       if (FRONT) {
-        const uint64_t raw = __hip_atomic_load(reinterpret_cast<const uint64_t*>(rrow + m * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t raw = __hip_atomic_load((const __attribute__((address_space(1))) uint64_t*)(gy + roff + m * 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
         rv = (f32x4){(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
       } else {
-        rv = Vec4<bf16_t>::load(rrow + m * 16);
+        rv = cvt4(*(const __attribute__((address_space(1))) bf16x4*)(gx + roff + m * 32));
       }
       out[m][j] += p.alpha * rv;
 #pragma unroll
@@ -411,7 +424,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
     }
     const bool odd = kq & 1;
-    bf16_t* yrow = p.y + (size_t)tc * p.ldy;
+    const uint32_t yoff = ((uint32_t)tc * (uint32_t)p.ldy + (odd ? 16 + kq * 4 - 4 : kq * 4)) * 2u;   // + 64 bytes per ip
 #pragma unroll
     for (int ip = 0; ip < 8; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
@@ -430,8 +443,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       recv.x = __shfl_xor(send.x, 16, 64);
       recv.y = __shfl_xor(send.y, 16, 64);
       const uint4 ov = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
-      const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
-      if (tv && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = ov;
+      if (tv && !(p.debug & 1)) *(__attribute__((address_space(1))) u32x4_t*)(gy + yoff + ip * 64) = (u32x4_t){ov.x, ov.y, ov.z, ov.w};
     }
   }
   MLP_STAMP();
