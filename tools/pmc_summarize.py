@@ -19,6 +19,7 @@ CLASS_OF = (            # kernel-name fragment -> bench.py --kernel class
     ("k_attn_bf16<", "attention"),
     ("k_gemm_k256<1,", "gemm_qkv"),
     ("k_gemm_k256<2,", "gemm_geglu"),
+    ("k_mlp256<", "layer_tail"),
     ("k_gemm_rowtile_norm", "gemm_w3_keel"),
     ("k_gemm_k256_rownorm", "gemm_out_keel"),
 )
