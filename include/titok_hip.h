@@ -284,6 +284,12 @@ int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_
 /* counts[idx] += 1 for every index (int64 device histogram, atomics); usage/entropy are finished on the host. */
 int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int codebook_size, void* stream);
 
+/* L1 reconstruction term of the generator loss (loss_module.py:118 per clip, mean over clips - train.py:70), value and
+ * gradient in one launch: *loss += mean_c mean_i |recon_c[i] - target_c[i]| (caller zeroes it);
+ * grad_c[i] = sign(recon - target) / (sizes[c] * n_clips) in `dtype` (grad NULL = value only).  Host arrays of device pointers. */
+int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, const int32_t* sizes, int n_clips, int dtype, float* loss,
+                void* stream);
+
 /* ---- measurement hook (bench.py roofline leg) ---------------------------------------------------------- */
 /* Kernel classes whose launches can be bracketed by HIP events on the stream they are launched on. */
 #define TTV_KC_ATTENTION 1

@@ -255,3 +255,24 @@ def test_training_step_updates_weights_like_reference():
     opt_ref.step(); opt.step()
     for (n, p), r in zip(model.named_parameters(), params_ref):
         assert rel(p.detach(), r.detach()) < 1e-5, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_l1_loss_matches_autograd(dt):
+    """ttv_l1_loss (value + gradient, one launch) vs torch autograd over the per-clip definition (loss_module.py:118)."""
+    from titok_video_amd.train import l1_reconstruction_loss
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3, 4, 16, 16), (3, 8, 32, 48), (3, 4, 8, 24)]
+    recon = [torch.randn(sh, generator=g).to(dt) for sh in shapes]
+    target = [torch.randn(sh, generator=g).to(dt) for sh in shapes]
+    target[0][0, 0, 0, :4] = recon[0][0, 0, 0, :4]                            # exact ties -> zero gradient
+    ref_in = [r.clone().float().requires_grad_(True) for r in recon]
+    ref = torch.stack([(r - t.float()).abs().mean() for r, t in zip(ref_in, target)]).mean()
+    ref.backward()
+    dev_in = [r.to("cuda:0").requires_grad_(True) for r in recon]
+    loss = l1_reconstruction_loss(dev_in, [t.to("cuda:0") for t in target])
+    (loss * 2.0).backward()
+    assert abs(float(loss) - float(ref)) < (1e-6 if dt == torch.float32 else 2e-3)
+    for a, b in zip(dev_in, ref_in):
+        torch.testing.assert_close(a.grad.float().cpu(), 2.0 * b.grad, rtol=1e-2 if dt == torch.bfloat16 else 1e-6, atol=1e-9)

@@ -350,6 +350,16 @@ int ttv_rope_table_build(const float* base_cos, const float* base_sin, int n_ids
   return ttvk_rope_build(base_cos, base_sin, n_ids, n_freqs, clip_desc, cu_seqlens, row_seq, rope_cs, total_rows, (hipStream_t)stream);
 }
 
+int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, const int32_t* sizes, int n_clips, int dtype, float* loss,
+                void* stream) {
+  // loss must be zeroed by the caller; clips are processed in groups of TTV_MAX_CLIPS_PER_LAUNCH
+  for (int c0 = 0; c0 < n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_l1_loss(recon + c0, target + c0, grad ? grad + c0 : nullptr, sizes + c0, n, n_clips, dtype, loss, (hipStream_t)stream));
+  }
+  return TTV_OK;
+}
+
 int ttv_debug_set(int flags) {
   g_ttv_debug = flags;
   return TTV_OK;

@@ -864,3 +864,51 @@ int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const v
   }
   return TTV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// L1 reconstruction term of the generator loss (model/losses/loss_module.py:118 applied per clip, train.py:70):
+//   loss = mean over clips of mean |target - recon| ; d loss / d recon[c][i] = sign(recon - target) / (n_c * B)
+// One launch for value and gradient of every clip (the per-clip torch ops cost ~10 launches per clip).
+// ------------------------------------------------------------------------------------------------
+struct L1Clips { const void* recon[TTV_MAX_CLIPS_PER_LAUNCH]; const void* target[TTV_MAX_CLIPS_PER_LAUNCH]; void* grad[TTV_MAX_CLIPS_PER_LAUNCH];
+                 int n[TTV_MAX_CLIPS_PER_LAUNCH]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_l1_loss(L1Clips c, float inv_clips, float* __restrict__ loss) {
+  __shared__ float red[4];
+  const int ci = blockIdx.y, n = c.n[ci];
+  const T* r = reinterpret_cast<const T*>(c.recon[ci]);
+  const T* t = reinterpret_cast<const T*>(c.target[ci]);
+  T* g = reinterpret_cast<T*>(c.grad[ci]);
+  const float w = inv_clips / (float)n;
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float d = (float)r[i] - (float)t[i];
+    acc += fabsf(d);
+    if (g) g[i] = (T)(d > 0.f ? w : (d < 0.f ? -w : 0.f));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * w);
+}
+
+int ttvk_l1_loss(void* const* recon, void* const* target, void* const* grad, const int* sizes, int n_clips, int total_clips, int dtype,
+                 float* loss, hipStream_t s) {
+  TTV_CHECK_ARG(n_clips >= 0 && n_clips <= TTV_MAX_CLIPS_PER_LAUNCH && total_clips >= n_clips, "l1_loss: at most %d clips per call", TTV_MAX_CLIPS_PER_LAUNCH);
+  if (n_clips == 0) return TTV_OK;
+  TTV_CHECK_ARG(recon && target && sizes && loss, "l1_loss: null argument");
+  L1Clips c;
+  int mx = 0;
+  for (int i = 0; i < n_clips; ++i) {
+    c.recon[i] = recon[i]; c.target[i] = target[i]; c.grad[i] = grad ? grad[i] : nullptr; c.n[i] = sizes[i];
+    TTV_CHECK_ARG(sizes[i] > 0 && recon[i] && target[i], "l1_loss: empty clip");
+    mx = sizes[i] > mx ? sizes[i] : mx;
+  }
+  int bx = ttv_cdiv(mx, 256 * 8);
+  bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_l1_loss<bf16_t>), dim3(bx, n_clips), dim3(256), 0, s, c, 1.0f / (float)total_clips, loss);
+  else hipLaunchKernelGGL((k_l1_loss<float>), dim3(bx, n_clips), dim3(256), 0, s, c, 1.0f / (float)total_clips, loss);
+  TTV_CHECK_LAUNCH("l1_loss");
+  return TTV_OK;
+}

@@ -67,6 +67,8 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
                    int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, hipStream_t s);
 
 // ---- ttv_bwd.hip (backward kernels) ----
+int ttvk_l1_loss(void* const* recon, void* const* target, void* const* grad, const int* sizes, int n_clips, int total_clips, int dtype,
+                 float* loss, hipStream_t s);
 int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void* dy, int dy_dt, int lddy, const int* dyr,
                      const float* gain, void* dx, int dx_dt, int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps,
                      hipStream_t s);

@@ -6,13 +6,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from titok_video_amd.model.titok import TiTok
 from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
-from titok_video_amd.train import make_optimizer, training_step
+from titok_video_amd.train import freeze_python_gc, make_optimizer, training_step
 B = int(os.environ.get("B", "32"))
 cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5], encoder_size="tiny", decoder_size="tiny")))
 m = TiTok(cfg); m.load_state_dict(seeded_titok_state(0)); m = m.to("cuda:0", torch.bfloat16).train()
 clips = synthetic_clips([(16, 128, 128)] * B, seed=1, dtype=torch.bfloat16, device="cuda:0")
 counts = [128] * B
 opt = make_optimizer(m)
+if os.environ.get("GC_FREEZE", "1") == "1":
+    freeze_python_gc()
 for _ in range(3):
     training_step(m, clips, counts, opt)
 torch.cuda.synchronize()
