@@ -33,49 +33,72 @@ __global__ __launch_bounds__(256) void k_rmsnorm_bwd(const TX* __restrict__ x, i
   for (int it = 0; it < BW_MAX_ITERS; ++it)
 #pragma unroll
     for (int e = 0; e < 4; ++e) dg[it][e] = 0.f;
+  // RB rows in flight per wave: a single row is a chain of dependent steps (loads -> wave reduction -> second reduction ->
+  // store, ~2 us); with the block count held at ~256 for the gain atomics there is one wave per SIMD, so the overlap has to
+  // come from independent rows inside the wave
+  constexpr int RB = 4;
   const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave;
-  for (int r = r0; r < r0 + rows_per_wave && r < rows; ++r) {
-    const TX* px = x + (size_t)(x_rows ? x_rows[r] : r) * ldx;
-    const TG* pg = dy + (size_t)(dy_rows ? dy_rows[r] : r) * lddy;
-    f32x4 xv[BW_MAX_ITERS], gv[BW_MAX_ITERS];
-    float ss = 0.f;
+  const int r_end = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+  for (int rb = r0; rb < r_end; rb += RB) {
+    f32x4 xv[RB][BW_MAX_ITERS], gv[RB][BW_MAX_ITERS];
+    float ss[RB], dot[RB], rstd[RB];
+    bool live[RB];
 #pragma unroll
-    for (int it = 0; it < BW_MAX_ITERS; ++it) {
-      const int c = (it * 64 + lane) * 4;
-      if (c < d) {
-        xv[it] = Vec4<TX>::load(px + c);
-        gv[it] = Vec4<TG>::load(pg + c);
-        ss += xv[it][0] * xv[it][0] + xv[it][1] * xv[it][1] + xv[it][2] * xv[it][2] + xv[it][3] * xv[it][3];
-      }
-    }
-    ss = wave_sum(ss);
-    const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
-    float dot = 0.f;   // sum_f (dy*gain) * xhat
+    for (int q = 0; q < RB; ++q) {
+      const int r = rb + q;
+      live[q] = r < r_end;
+      const int rc = live[q] ? r : r_end - 1;
+      const TX* px = x + (size_t)(x_rows ? x_rows[rc] : rc) * ldx;
+      const TG* pg = dy + (size_t)(dy_rows ? dy_rows[rc] : rc) * lddy;
+      ss[q] = 0.f;
 #pragma unroll
-    for (int it = 0; it < BW_MAX_ITERS; ++it) {
-      const int c = (it * 64 + lane) * 4;
-      if (c < d) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xh = xv[it][e] * rstd;
-          dg[it][e] += gv[it][e] * xh;
-          gv[it][e] *= g[e];
-          dot += gv[it][e] * xh;
+      for (int it = 0; it < BW_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < d) {
+          xv[q][it] = Vec4<TX>::load(px + c);
+          gv[q][it] = Vec4<TG>::load(pg + c);
+          ss[q] += xv[q][it][0] * xv[q][it][0] + xv[q][it][1] * xv[q][it][1] + xv[q][it][2] * xv[q][it][2] + xv[q][it][3] * xv[q][it][3];
         }
       }
     }
-    dot = wave_sum(dot) / (float)d;
-    TO* pd = dx + (size_t)(dx_rows ? dx_rows[r] : r) * lddx;
 #pragma unroll
-    for (int it = 0; it < BW_MAX_ITERS; ++it) {
-      const int c = (it * 64 + lane) * 4;
-      if (c < d) {
-        f32x4 o;
+    for (int q = 0; q < RB; ++q) ss[q] = wave_sum(ss[q]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[it][e] - xv[it][e] * rstd * dot);
-        if (accumulate) o += Vec4<TO>::load(pd + c);
-        Vec4<TO>::store(pd + c, o);
+    for (int q = 0; q < RB; ++q) {
+      rstd[q] = 1.0f / sqrtf(ss[q] / (float)d + eps);
+      dot[q] = 0.f;   // sum_f (dy*gain) * xhat
+#pragma unroll
+      for (int it = 0; it < BW_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < d) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = xv[q][it][e] * rstd[q];
+            if (live[q]) dg[it][e] += gv[q][it][e] * xh;
+            gv[q][it][e] *= g[e];
+            dot[q] += gv[q][it][e] * xh;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) dot[q] = wave_sum(dot[q]) / (float)d;
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      if (!live[q]) continue;
+      const int r = rb + q;
+      TO* pd = dx + (size_t)(dx_rows ? dx_rows[r] : r) * lddx;
+#pragma unroll
+      for (int it = 0; it < BW_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < d) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rstd[q] * (gv[q][it][e] - xv[q][it][e] * rstd[q] * dot[q]);
+          if (accumulate) o += Vec4<TO>::load(pd + c);
+          Vec4<TO>::store(pd + c, o);
+        }
       }
     }
   }
