@@ -652,6 +652,22 @@ __device__ __forceinline__ void stage_tile64(uint4* dst, const bf16_t* src, int 
     dst[r * 8 + c] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
   }
 }
+// The same staging split in two so that the global loads of the NEXT tile are in flight while the current one is used
+struct TileRegs { uint4 v[2]; };
+__device__ __forceinline__ TileRegs load_tile64(const bf16_t* src, int ld, int row0, int row_end, int tid) {
+  TileRegs t;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 3) + 32 * i, c = tid & 7;
+    t.v[i] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
+  }
+  return t;
+}
+__device__ __forceinline__ void store_tile64(uint4* dst, const TileRegs& t, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dst[((tid >> 3) + 32 * i) * 8 + (tid & 7)] = t.v[i];
+}
 // fragment with 8 consecutive COLUMNS of one row (K-contiguous operand): rows r0+l15, columns kc*8.. (b128)
 __device__ __forceinline__ bf16x8 frag_row(const uint4* tile, int row, int chunk) { return __builtin_bit_cast(bf16x8, tile[row * 8 + chunk]); }
 // fragment with 8 consecutive ROWS (row0 + 8*kq + 0..7) of one column col0 + l15: two transposed reads
@@ -733,16 +749,32 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  for (int hr = 0; hr < rep; ++hr) {
-    const int h = kvh * rep + hr;
-    for (int q0 = 0; q0 < S; q0 += 64) {
+  // the (q-head, 64-query block) pairs are walked as one sequence; the tiles of step n+1 are loaded to registers while step n
+  // computes (the loop used to expose a full global-load latency per step)
+  const int nqb = (S + 63) / 64, nsteps = rep * nqb;
+  const bf16_t* dbase = dout + (size_t)s0 * ldd;
+  TileRegs rq = load_tile64(base + (kvh * rep) * 64, ld, 0, S, tid), rd = load_tile64(dbase + (kvh * rep) * 64, ldd, 0, S, tid);
+  float rl = 0.f, rdl = 0.f;
+  if (tid < 64) {
+    rl = tid < S ? lse[(size_t)(s0 + tid) * hq + kvh * rep] : 0.f;
+    rdl = tid < S ? delta[(size_t)(s0 + tid) * hq + kvh * rep] : 0.f;
+  }
+  for (int step = 0; step < nsteps; ++step) {
+    const int hr = step / nqb, q0 = (step - hr * nqb) * 64;
+    {
       __syncthreads();
-      stage_tile64(qt, base + h * 64, ld, q0, S, tid);
-      stage_tile64(dt_, dout + (size_t)s0 * ldd + h * 64, ldd, q0, S, tid);
-      if (tid < 64) {
-        const int q = q0 + tid;
-        lse_s[tid] = q < S ? lse[(size_t)(s0 + q) * hq + h] : 0.f;
-        delta_s[tid] = q < S ? delta[(size_t)(s0 + q) * hq + h] : 0.f;
+      store_tile64(qt, rq, tid);
+      store_tile64(dt_, rd, tid);
+      if (tid < 64) { lse_s[tid] = rl; delta_s[tid] = rdl; }
+      if (step + 1 < nsteps) {
+        const int hr1 = (step + 1) / nqb, q1 = (step + 1 - hr1 * nqb) * 64, h1 = kvh * rep + hr1;
+        rq = load_tile64(base + h1 * 64, ld, q1, S, tid);
+        rd = load_tile64(dbase + h1 * 64, ldd, q1, S, tid);
+        if (tid < 64) {
+          const int q = q1 + tid;
+          rl = q < S ? lse[(size_t)(s0 + q) * hq + h1] : 0.f;
+          rdl = q < S ? delta[(size_t)(s0 + q) * hq + h1] : 0.f;
+        }
       }
       __syncthreads();
       const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
@@ -821,10 +853,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) dq[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  TileRegs rk = load_tile64(base + 2 * d_model + kvh * 64, ld, 0, S, tid), rv = load_tile64(base + 2 * d_model + gqa + kvh * 64, ld, 0, S, tid);
   for (int key0 = 0; key0 < S; key0 += 64) {
     __syncthreads();
-    stage_tile64(kt, base + 2 * d_model + kvh * 64, ld, key0, S, tid);
-    stage_tile64(vt, base + 2 * d_model + gqa + kvh * 64, ld, key0, S, tid);
+    store_tile64(kt, rk, tid);
+    store_tile64(vt, rv, tid);
+    if (key0 + 64 < S) {   // next K/V tiles in flight behind this step's MFMAs
+      rk = load_tile64(base + 2 * d_model + kvh * 64, ld, key0 + 64, S, tid);
+      rv = load_tile64(base + 2 * d_model + gqa + kvh * 64, ld, key0 + 64, S, tid);
+    }
     __syncthreads();
     const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
 #pragma unroll
