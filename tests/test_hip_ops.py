@@ -233,7 +233,7 @@ def test_linear_residual_norm_fused(M, K):
     assert rc == 3      # TTV_ERR_UNSUPPORTED: callers fall back to linear_residual + rmsnorm
 
 
-@pytest.mark.parametrize("M", [1, 100, 192, 200, 1000, 50000])
+@pytest.mark.parametrize("M", [1, 100, 192, 200, 1000, 20000, 50000])   # 64-, 128- and 192-token tile variants
 @pytest.mark.parametrize("keel", [True, False])
 @pytest.mark.parametrize("I", [704, 96, 32])
 def test_mlp_fused(M, keel, I):
@@ -265,7 +265,7 @@ def test_mlp_fused(M, keel, I):
                              _lib.TTV_BF16, S()) == 3
 
 
-@pytest.mark.parametrize("M", [1, 100, 192, 1000, 40000])
+@pytest.mark.parametrize("M", [1, 100, 192, 1000, 20000, 40000])
 @pytest.mark.parametrize("keel", [True, False])
 def test_layer_tail_fused(M, keel):
     """out_proj + residual/KEEL + GEGLU sub-layer + residual/KEEL in one kernel vs the op-by-op definition

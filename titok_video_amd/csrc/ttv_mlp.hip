@@ -110,6 +110,7 @@ template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL, bool FRO
 __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3, uint4* hb, const float* gl, int tile, int wave, int lane,
                                          int& n_stamp) {
   constexpr int T2 = NT - T1;
+  constexpr int T1A = T1 > 0 ? T1 : 1, T2A = T2 > 0 ? T2 : 1;   // array extents (a role may have no P1 or no P2 tile: NT = 1)
   const int w4 = wave & 3, l15 = lane & 15, kq = lane >> 4;
   const int np = p.I / 32;
   // LDS-DMA of one image by all 8 waves: wave w copies KiB blocks w, w+8, ... (64 lanes x 16 B, lane-linear on both
@@ -141,8 +142,8 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   MLP_STAMP();
   __syncthreads();   // every wave is done with the previous tile's LDS contents
 
-  bf16x8 bfr[T1][8];   // x rows of the P1 tiles as B fragments, k order per 32-step: {4kq..+3, 16+4kq..+3}
-  float rstd[T1];
+  bf16x8 bfr[T1A][8];   // x rows of the P1 tiles as B fragments, k order per 32-step: {4kq..+3, 16+4kq..+3}
+  float rstd[T1A];
   if (FRONT) {
     // ---- fused front: x' = [RMSNorm](fa*x + ao Wo^T)[*fg] for the P1 tiles (the wave then owns all 256 features of its
     // tokens in C layout, which IS the B-fragment layout above); Wo streams through the W12 buffers as 4 panel images ----
@@ -153,7 +154,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
   } while (0)
     GLDS_WO(0, 0);
-    bf16x8 abf[T1][8];
+    bf16x8 abf[T1A][8];
 #pragma unroll
     for (int j = 0; j < T1; ++j) {
       const int t = tok0 + 16 * (P1F + j);
@@ -162,7 +163,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) abf[j][s8] = *(const __attribute__((address_space(1))) bf16x8*)(gao + aoff + s8 * 64);
     }
-    f32x4 facc[16][T1];
+    f32x4 facc[16][T1A];
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 #pragma unroll
@@ -170,6 +171,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       if (wp + 1 < 4) GLDS_WO(wp + 1, (wp + 1) & 1);
       const uint4* img = l12 + (wp & 1) * MLP_W12_CHUNKS;
       bf16x8 a[2][4];
+      if constexpr (T1 > 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[0][i] = MLP_LD12(img, i, 0);
 #pragma unroll
@@ -185,8 +187,9 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
             facc[4 * wp + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], abf[j][s8],
                                                                            s8 ? facc[4 * wp + i][j] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T1A, 0);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
@@ -275,7 +278,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     }
   }
   // ---- P2 tiles: y accumulators ----
-  f32x4 out[16][T2];
+  f32x4 out[16][T2A];
 #pragma unroll
   for (int m = 0; m < 16; ++m)
 #pragma unroll
@@ -289,8 +292,8 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     if (it + 1 < np && !(p.debug & 2)) GLDS_W12(it + 1, (it + 1) & 1);
     if (it < np && (!(p.debug & 2) || it == 0)) GLDS_W3(it, it & 1);
 
-    f32x4 acc1[4][T1];   // [x 0..15, x 16..31, gate 0..15, gate 16..31][P1 token tile]
-    if (it < np) {
+    f32x4 acc1[4][T1A];   // [x 0..15, x 16..31, gate 0..15, gate 16..31][P1 token tile]
+    if (T1 > 0 && it < np) {
       // ---- P1 MFMAs of panel `it`: A fragments double-buffered in registers, reads pinned ahead of their MFMAs ----
       const uint4* img = l12 + (it & 1) * MLP_W12_CHUNKS;
       bf16x8 a[2][4];
@@ -309,19 +312,19 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
             acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], bfr[j][s8],
                                                                   s8 ? acc1[i][j] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T1A, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     // GELU_FIRST swaps the order of the two remaining parts (measured: both waves P2-before-GEGLU is the faster setting -
     // the P2 MFMAs cover the latency of the P1 results the GEGLU reads)
     if (!GELU_FIRST) {
-      if (it >= 1 && !(p.debug & 16)) {
+      if (T2 > 0 && it >= 1 && !(p.debug & 16)) {
         // ---- P2 MFMAs of panel it-1: y^T += W3slice h^T ----
         const int pn = it - 1;
         const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
         const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT + P2F) * 64 + lane;
-        bf16x8 hf[T2];
+        bf16x8 hf[T2A];
   #pragma unroll
         for (int j = 0; j < T2; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
         bf16x8 w3f[4];
@@ -332,13 +335,13 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   #pragma unroll
           for (int j = 0; j < T2; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[m & 3], hf[j], out[m][j], 0, 0, 0);
           if (m + 4 < 16) w3f[m & 3] = __builtin_bit_cast(bf16x8, w3l[(m + 4) * 16]);
-          __builtin_amdgcn_sched_group_barrier(0x008, T2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, T2A, 0);
           if (m + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    if (it < np) {
+    if (T1 > 0 && it < np) {
       // ---- GEGLU of panel `it` in registers -> one B fragment of the second product per token tile ----
       uint4* hdst = hb + (((it & 1) * 4 + w4) * NT + P1F) * 64 + lane;
 #pragma unroll
@@ -363,12 +366,12 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       }
     }
     if (GELU_FIRST) {
-      if (it >= 1 && !(p.debug & 16)) {
+      if (T2 > 0 && it >= 1 && !(p.debug & 16)) {
         // ---- P2 MFMAs of panel it-1: y^T += W3slice h^T ----
         const int pn = it - 1;
         const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
         const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT + P2F) * 64 + lane;
-        bf16x8 hf[T2];
+        bf16x8 hf[T2A];
   #pragma unroll
         for (int j = 0; j < T2; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
         bf16x8 w3f[4];
@@ -379,7 +382,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   #pragma unroll
           for (int j = 0; j < T2; ++j) out[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[m & 3], hf[j], out[m][j], 0, 0, 0);
           if (m + 4 < 16) w3f[m & 3] = __builtin_bit_cast(bf16x8, w3l[(m + 4) * 16]);
-          __builtin_amdgcn_sched_group_barrier(0x008, T2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, T2A, 0);
           if (m + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -504,10 +507,18 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
   d.x = (const bf16_t*)x; d.ldx = ldx; d.pack = (const uint4*)packed; d.I = inner;
   d.ao = (const bf16_t*)ao; d.ldao = ldao; d.front_gain = front_gain; d.front_alpha = front_alpha;
   d.y = (bf16_t*)y; d.ldy = ldy; d.post_gain = post_gain; d.alpha = alpha; d.eps = eps; d.M = M; d.debug = g_ttv_debug; d.stamps = g_ttv_stamps;
-  // tokens per wave pair (NT*16): pick the tile size that needs the fewest full rounds of the 256 CUs, weighted by tile cost
+  // tokens per wave pair (NT*16): tile size with the smallest (rounds over the 256 CUs) x (cost of one tile); a tile costs
+  // about 16 + 19*NT us (measured: 54 us at NT = 2, 73 us at NT = 3), so small batches - the reference trains under a
+  // 6144-token budget, configs/tiny.yaml:65 - take 64-token tiles on many CUs rather than a few CUs with fat tiles
   const int cus = 256;
-  const long c2 = (long)ttv_cdiv(ttv_cdiv(M, 128), cus) * 2, c3 = (long)ttv_cdiv(ttv_cdiv(M, 192), cus) * 3;
-  const int nt = (c3 < c2 && !(g_ttv_debug & 8)) ? 3 : 2;   // debug bit3 forces the 2-tile variant
+  int nt = 1;
+  long best = -1;
+  for (int c = 1; c <= 3; ++c) {
+    const long cost = (long)ttv_cdiv(ttv_cdiv(M, 64 * c), cus) * (16 + 19 * c);
+    if (best < 0 || cost < best) { best = cost; nt = c; }
+  }
+  if (g_ttv_debug & 8) nt = 2;     // debug bit3 forces the 2-tile variant
+  if (g_ttv_debug & 64) nt = 1;    // debug bit6 forces the 1-tile variant
   d.n_tiles = ttv_cdiv(M, 64 * nt);
   const int grid = d.n_tiles < cus ? d.n_tiles : cus;
   const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4) + 2048;   // 96 KiB + 8 KiB per token tile + gains
@@ -518,8 +529,8 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
     hipLaunchKernelGGL((k_mlp256<NT_, KEEL_, FRONT_>), dim3(grid), dim3(512), smem, s, d);                          \
   } while (0)
 #define LAUNCH_MLP_F(NT_, KEEL_) do { if (ao) LAUNCH_MLP(NT_, KEEL_, true); else LAUNCH_MLP(NT_, KEEL_, false); } while (0)
-  if (post_gain) { if (nt == 3) LAUNCH_MLP_F(3, true); else LAUNCH_MLP_F(2, true); }
-  else { if (nt == 3) LAUNCH_MLP_F(3, false); else LAUNCH_MLP_F(2, false); }
+  if (post_gain) { if (nt == 3) LAUNCH_MLP_F(3, true); else if (nt == 2) LAUNCH_MLP_F(2, true); else LAUNCH_MLP_F(1, true); }
+  else { if (nt == 3) LAUNCH_MLP_F(3, false); else if (nt == 2) LAUNCH_MLP_F(2, false); else LAUNCH_MLP_F(1, false); }
 #undef LAUNCH_MLP_F
 #undef LAUNCH_MLP
   TTV_CHECK_LAUNCH("mlp_fused");
