@@ -726,13 +726,32 @@ __device__ __forceinline__ PdS attn_recompute(const uint4* kt, const uint4* vt, 
   return r;
 }
 
+// Fragment for a contraction over 32 ROWS of a row-major tile taken in the order of a C-layout accumulator pair
+// (lane group kq: rows row0 + {4kq..4kq+3, 16+4kq..16+4kq+3}), for column col0 + l15: two transposed reads.
+// With it, the S / dS accumulators of the first product ARE the B operand of the second one (packed to bf16):
+// no LDS round trip and no barrier between the two products.
+__device__ __forceinline__ bf16x8 frag_colp(const uint4* tile, int row0, int col0, int lane) {
+  const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, kq = lane >> 4;
+  const char* b = reinterpret_cast<const char*>(tile) + (row0 + kq * 4 + tq) * 128 + (col0 + tp * 4) * 2;
+  const bf16x4 lo = tr16(b), hi = tr16(b + 16 * 128);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 pack_pair(f32x4 lo, f32x4 hi) {
+  return (bf16x8){(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+}
+
 // dK, dV of one 64-key block of one (sequence, kv-head): loops over the group's q-heads and all 64-query blocks.
+// Wave (wa, wb) recomputes S[q][key] / dP[q][key] for queries wa*32.. (MFMA rows) x keys wb*32.. (columns): a lane then holds
+// 4 consecutive QUERIES of one key column, i.e. the B fragment of the products contracted over queries,
+//   dV^T[d][key] += dO^T[d][q] P[q][key],   dK^T[d][key] += Q^T[d][q] dS[q][key],
+// whose A operands are transposed reads of the dO / Q tiles.  Each wave accumulates all 64 d for its 32 keys over its 32
+// queries; the two waves of a key half are summed once at the end.
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       const int* __restrict__ cu, const int* __restrict__ blocks, bf16_t* __restrict__ dqkvg,
                                                       int ldg, int hq, int hkv, float scale) {
-  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], pt[512], st[512];
-  __shared__ float lse_s[64], delta_s[64];
+  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], red[2048];
+  __shared__ __attribute__((aligned(16))) float lse_s[64], delta_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave & 1, wb = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
@@ -743,14 +762,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
   const bf16_t* base = qkvg + (size_t)s0 * ld;
   stage_tile64(kt, base + 2 * d_model + kvh * 64, ld, key0, S, tid);
   stage_tile64(vt, base + 2 * d_model + gqa + kvh * 64, ld, key0, S, tid);
-  // accumulators: dK^T / dV^T tiles with rows = d (A operand = transposed Q / dO), cols = key: wave owns d (wa*32..) x key (wb*32..)
-  f32x4 dk[2][2], dv[2][2];
+  f32x4 dk[4][2], dv[4][2];   // [d tile][key tile of this wave]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   // the (q-head, 64-query block) pairs are walked as one sequence; the tiles of step n+1 are loaded to registers while step n
-  // computes (the loop used to expose a full global-load latency per step)
+  // computes
   const int nqb = (S + 63) / 64, nsteps = rep * nqb;
   const bf16_t* dbase = dout + (size_t)s0 * ldd;
   TileRegs rq = load_tile64(base + (kvh * rep) * 64, ld, 0, S, tid), rd = load_tile64(dbase + (kvh * rep) * 64, ldd, 0, S, tid);
@@ -761,76 +779,111 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
   }
   for (int step = 0; step < nsteps; ++step) {
     const int hr = step / nqb, q0 = (step - hr * nqb) * 64;
-    {
-      __syncthreads();
-      store_tile64(qt, rq, tid);
-      store_tile64(dt_, rd, tid);
-      if (tid < 64) { lse_s[tid] = rl; delta_s[tid] = rdl; }
-      if (step + 1 < nsteps) {
-        const int hr1 = (step + 1) / nqb, q1 = (step + 1 - hr1 * nqb) * 64, h1 = kvh * rep + hr1;
-        rq = load_tile64(base + h1 * 64, ld, q1, S, tid);
-        rd = load_tile64(dbase + h1 * 64, ldd, q1, S, tid);
-        if (tid < 64) {
-          const int q = q1 + tid;
-          rl = q < S ? lse[(size_t)(s0 + q) * hq + h1] : 0.f;
-          rdl = q < S ? delta[(size_t)(s0 + q) * hq + h1] : 0.f;
-        }
+    __syncthreads();
+    store_tile64(qt, rq, tid);
+    store_tile64(dt_, rd, tid);
+    if (tid < 64) { lse_s[tid] = rl; delta_s[tid] = rdl; }
+    if (step + 1 < nsteps) {
+      const int hr1 = (step + 1) / nqb, q1 = (step + 1 - hr1 * nqb) * 64, h1 = kvh * rep + hr1;
+      rq = load_tile64(base + h1 * 64, ld, q1, S, tid);
+      rd = load_tile64(dbase + h1 * 64, ldd, q1, S, tid);
+      if (tid < 64) {
+        const int q = q1 + tid;
+        rl = q < S ? lse[(size_t)(s0 + q) * hq + h1] : 0.f;
+        rdl = q < S ? delta[(size_t)(s0 + q) * hq + h1] : 0.f;
       }
-      __syncthreads();
-      const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
-      // P^T / dS^T -> LDS as [query][key] (lane holds 4 consecutive keys of one query: one 8-byte store each)
+    }
+    __syncthreads();
+    // S[q][key], dP[q][key]: A = Q / dO rows (queries), B = K / V rows (keys)
+    f32x4 sp[2][2], dp[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { sp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 aq[2], ad[2], bk[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        aq[i] = frag_row(qt, wa * 32 + i * 16 + l15, ks * 4 + kq);
+        ad[i] = frag_row(dt_, wa * 32 + i * 16 + l15, ks * 4 + kq);
+        bk[i] = frag_row(kt, wb * 32 + i * 16 + l15, ks * 4 + kq);
+        bv[i] = frag_row(vt, wb * 32 + i * 16 + l15, ks * 4 + kq);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int qi = wb * 32 + j * 16 + l15, kc = wa * 32 + i * 16 + kq * 4;
-          const bf16x4 pb = {(bf16_t)r.p[i][j][0], (bf16_t)r.p[i][j][1], (bf16_t)r.p[i][j][2], (bf16_t)r.p[i][j][3]};
-          const bf16x4 sb = {(bf16_t)r.ds[i][j][0], (bf16_t)r.ds[i][j][1], (bf16_t)r.ds[i][j][2], (bf16_t)r.ds[i][j][3]};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(pt) + qi * 128 + kc * 2) = pb;
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(st) + qi * 128 + kc * 2) = sb;
+          sp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bk[j], sp[i][j], 0, 0, 0);
+          dp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[i], bv[j], dp[i][j], 0, 0, 0);
         }
-      __syncthreads();
-      // dV^T[d][key] += sum_q dO^T[d][q] P[q][key] ; dK^T[d][key] += sum_q Q^T[d][q] dS[q][key]   (contraction over queries)
+    }
+    // P = exp(S*scale - lse[q]), dS = P (dP - delta[q]) scale ; lane: queries wa*32 + i*16 + 4kq + e (rows), key column l15
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        bf16x8 ado[2], aq[2], bp[2], bs[2];
+    for (int i = 0; i < 2; ++i) {
+      const int qb = wa * 32 + i * 16 + kq * 4;
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb), d4 = *reinterpret_cast<const f32x4*>(delta_s + qb);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ado[i] = frag_col(dt_, qs * 32, wa * 32 + i * 16, lane);   // rows = d, k = queries
-          aq[i] = frag_col(qt, qs * 32, wa * 32 + i * 16, lane);
-          bp[i] = frag_col(pt, qs * 32, wb * 32 + i * 16, lane);     // cols = key, k = queries
-          bs[i] = frag_col(st, qs * 32, wb * 32 + i * 16, lane);
+      for (int j = 0; j < 2; ++j) {
+        const bool kv_ok = key0 + wb * 32 + j * 16 + l15 < S;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = (kv_ok && q0 + qb + e < S) ? __expf(sp[i][j][e] * scale - l4[e]) : 0.f;
+          dp[i][j][e] = pv * (dp[i][j][e] - d4[e]) * scale;
+          sp[i][j][e] = pv;
         }
+      }
+    }
+    bf16x8 bp[2], bs[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) { bp[j] = pack_pair(sp[0][j], sp[1][j]); bs[j] = pack_pair(dp[0][j], dp[1][j]); }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            dv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[i], bp[j], dv[i][j], 0, 0, 0);
-            dk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bs[j], dk[i][j], 0, 0, 0);
-          }
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8 ado = frag_colp(dt_, wa * 32, i * 16, lane);   // rows = d (16 i + l15), k = this wave's 32 queries
+      const bf16x8 aqt = frag_colp(qt, wa * 32, i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        dv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado, bp[j], dv[i][j], 0, 0, 0);
+        dk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqt, bs[j], dk[i][j], 0, 0, 0);
       }
     }
   }
-  // lane: 4 consecutive d (rows) of key (col) l15
+  // sum the two query halves: wave wa keeps d tiles {2wa, 2wa+1} and receives them from its partner
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int key = key0 + wb * 32 + j * 16 + l15, d0 = wa * 32 + i * 16 + kq * 4;
+      const int io = (1 - wa) * 2 + i;   // the d tiles the partner keeps
+      red[(((wb * 2 + wa) * 2 + i) * 2 + j) * 128 + lane] = __builtin_bit_cast(uint4, dk[io][j]);
+      red[(((wb * 2 + wa) * 2 + i) * 2 + j) * 128 + 64 + lane] = __builtin_bit_cast(uint4, dv[io][j]);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ik = wa * 2 + i;
+      const f32x4 pk = __builtin_bit_cast(f32x4, red[(((wb * 2 + (1 - wa)) * 2 + i) * 2 + j) * 128 + lane]);
+      const f32x4 pv = __builtin_bit_cast(f32x4, red[(((wb * 2 + (1 - wa)) * 2 + i) * 2 + j) * 128 + 64 + lane]);
+      const int key = key0 + wb * 32 + j * 16 + l15, d0 = ik * 16 + kq * 4;   // lane: 4 consecutive d (rows) of key (col) l15
       if (key < S) {
         bf16_t* row = dqkvg + (size_t)(s0 + key) * ldg + 2 * d_model + kvh * 64 + d0;
-        Vec4<bf16_t>::store(row, dk[i][j]);
-        Vec4<bf16_t>::store(row + gqa, dv[i][j]);
+        Vec4<bf16_t>::store(row, dk[ik][j] + pk);
+        Vec4<bf16_t>::store(row + gqa, dv[ik][j] + pv);
       }
     }
 }
 
-// dQ of one 64-query block of one (sequence, q-head): loops over all 64-key blocks.
+// dQ of one 64-query block of one (sequence, q-head): loops over all 64-key blocks.  Wave (wa, wb) recomputes S^T / dP^T for
+// keys wa*32.. (MFMA rows) x queries wb*32.. (columns): a lane holds 4 consecutive KEYS of one query column = the B fragment of
+//   dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (contraction over keys; A = transposed read of the K tile).
+// Each wave accumulates all 64 d for its 32 queries over its 32 keys of every block; the two key halves are summed at the end.
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      const int* __restrict__ cu, const int* __restrict__ blocks, bf16_t* __restrict__ dqkvg,
                                                      int ldg, int hq, int hkv, float scale) {
-  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], st[512];
+  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], red[1024];
   __shared__ float lse_s[64], delta_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave & 1, wb = wave >> 1;
@@ -847,10 +900,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
     lse_s[tid] = q < S ? lse[(size_t)(s0 + q) * hq + h] : 0.f;
     delta_s[tid] = q < S ? delta[(size_t)(s0 + q) * hq + h] : 0.f;
   }
-  // dQ^T[d][q]: wave owns d (wa*32..) x q (wb*32..)
-  f32x4 dq[2][2];
+  f32x4 dq[4][2];   // [d tile][query tile of this wave]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) dq[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   TileRegs rk = load_tile64(base + 2 * d_model + kvh * 64, ld, 0, S, tid), rv = load_tile64(base + 2 * d_model + gqa + kvh * 64, ld, 0, S, tid);
@@ -864,36 +916,31 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
     }
     __syncthreads();
     const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
+    bf16x8 bs[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) bs[j] = pack_pair(r.ds[0][j], r.ds[1][j]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int qi = wb * 32 + j * 16 + l15, kc = wa * 32 + i * 16 + kq * 4;
-        const bf16x4 sb = {(bf16_t)r.ds[i][j][0], (bf16_t)r.ds[i][j][1], (bf16_t)r.ds[i][j][2], (bf16_t)r.ds[i][j][3]};
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(st) + qi * 128 + kc * 2) = sb;
-      }
-    __syncthreads();
-    // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]: A rows = d (K tile transposed), B cols = q with k = keys (row read of dS[q][key])
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8 a = frag_colp(kt, wa * 32, i * 16, lane);   // rows = d (16 i + l15), k = this wave's 32 keys
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = frag_col(kt, ks * 32, wa * 32 + i * 16, lane);
-        b[i] = frag_row(st, wb * 32 + i * 16 + l15, ks * 4 + kq);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dq[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], dq[i][j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) dq[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bs[j], dq[i][j], 0, 0, 0);
     }
   }
+  // sum the two key halves: wave wa keeps d tiles {2wa, 2wa+1}
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) red[(((wb * 2 + wa) * 2 + i) * 2 + j) * 64 + lane] = __builtin_bit_cast(uint4, dq[(1 - wa) * 2 + i][j]);
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int q = q0 + wb * 32 + j * 16 + l15, d0 = wa * 32 + i * 16 + kq * 4;
-      if (q < S) Vec4<bf16_t>::store(dqkvg + (size_t)(s0 + q) * ldg + h * 64 + d0, dq[i][j]);
+      const int ik = wa * 2 + i;
+      const f32x4 pq = __builtin_bit_cast(f32x4, red[(((wb * 2 + (1 - wa)) * 2 + i) * 2 + j) * 64 + lane]);
+      const int q = q0 + wb * 32 + j * 16 + l15, d0 = ik * 16 + kq * 4;
+      if (q < S) Vec4<bf16_t>::store(dqkvg + (size_t)(s0 + q) * ldg + h * 64 + d0, dq[ik][j] + pq);
     }
 }
 
