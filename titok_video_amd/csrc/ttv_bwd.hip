@@ -642,14 +642,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd_f32(const float* __restrict__ 
   dqkvg[(size_t)t * ldg + h * 64 + lane] = dq;
 }
 
-// ---- bf16 MFMA kernels.  LDS tiles are row-major [64 rows][64 cols] bf16 with 128-byte rows. ----
+// ---- bf16 MFMA kernels.  LDS tiles are row-major [64 rows][64 cols] bf16 with 128-byte rows; the 16-byte chunk c of row r
+// is stored at chunk position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 fragment read touches then cover all 64
+// banks once (unswizzled they fall on two 4-bank groups, 8-way), and the transposed reads drop from 4-way to 2-way. ----
+#define TSW(r_) (((r_) >> 1) & 7)
 __device__ __forceinline__ void stage_tile64(uint4* dst, const bf16_t* src, int ld, int row0, int row_end, int tid) {
   // 64 rows x 8 chunks, 2 chunks per thread; rows past row_end are zero-filled
   const uint4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (tid >> 3) + 32 * i, c = tid & 7;
-    dst[r * 8 + c] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
+    dst[r * 8 + (c ^ TSW(r))] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
   }
 }
 // The same staging split in two so that the global loads of the NEXT tile are in flight while the current one is used
@@ -666,15 +669,21 @@ __device__ __forceinline__ TileRegs load_tile64(const bf16_t* src, int ld, int r
 }
 __device__ __forceinline__ void store_tile64(uint4* dst, const TileRegs& t, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) dst[((tid >> 3) + 32 * i) * 8 + (tid & 7)] = t.v[i];
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    dst[r * 8 + ((tid & 7) ^ TSW(r))] = t.v[i];
+  }
 }
 // fragment with 8 consecutive COLUMNS of one row (K-contiguous operand): rows r0+l15, columns kc*8.. (b128)
-__device__ __forceinline__ bf16x8 frag_row(const uint4* tile, int row, int chunk) { return __builtin_bit_cast(bf16x8, tile[row * 8 + chunk]); }
+__device__ __forceinline__ bf16x8 frag_row(const uint4* tile, int row, int chunk) { return __builtin_bit_cast(bf16x8, tile[row * 8 + (chunk ^ TSW(row))]); }
 // fragment with 8 consecutive ROWS (row0 + 8*kq + 0..7) of one column col0 + l15: two transposed reads
+__device__ __forceinline__ const char* tile_addr(const uint4* tile, int row, int col) {   // col % 4 == 0
+  return reinterpret_cast<const char*>(tile) + row * 128 + ((((col >> 3) ^ TSW(row)) << 4) | ((col & 7) << 1));
+}
 __device__ __forceinline__ bf16x8 frag_col(const uint4* tile, int row0, int col0, int lane) {
   const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, kq = lane >> 4;
-  const char* b = reinterpret_cast<const char*>(tile) + (row0 + kq * 8 + tq) * 128 + (col0 + tp * 4) * 2;
-  const bf16x4 lo = tr16(b), hi = tr16(b + 4 * 128);
+  const int r = row0 + kq * 8 + tq, c = col0 + tp * 4;
+  const bf16x4 lo = tr16(tile_addr(tile, r, c)), hi = tr16(tile_addr(tile, r + 4, c));
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -732,8 +741,8 @@ __device__ __forceinline__ PdS attn_recompute(const uint4* kt, const uint4* vt, 
 // no LDS round trip and no barrier between the two products.
 __device__ __forceinline__ bf16x8 frag_colp(const uint4* tile, int row0, int col0, int lane) {
   const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, kq = lane >> 4;
-  const char* b = reinterpret_cast<const char*>(tile) + (row0 + kq * 4 + tq) * 128 + (col0 + tp * 4) * 2;
-  const bf16x4 lo = tr16(b), hi = tr16(b + 16 * 128);
+  const int r = row0 + kq * 4 + tq, c = col0 + tp * 4;
+  const bf16x4 lo = tr16(tile_addr(tile, r, c)), hi = tr16(tile_addr(tile, r + 16, c));
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8 pack_pair(f32x4 lo, f32x4 hi) {
