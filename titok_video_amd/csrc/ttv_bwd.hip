@@ -118,7 +118,7 @@ static int launch_rms_bwd(const void* x, int ldx, const int* xr, const void* dy,
                           int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps, hipStream_t s) {
   // few, fat blocks: the gain gradient is one atomicAdd per column per BLOCK onto the same `d` addresses, so the block count
   // (not the row count) sets the contention; ~256 blocks keep every CU busy
-  int rpw = ttv_cdiv(rows, 4 * 256);
+  int rpw = ttv_cdiv(rows, 4 * 512);   // ~2 blocks per CU: the row loop is latency-bound, two waves per SIMD overlap it
   if (rpw < 1) rpw = 1;
   hipLaunchKernelGGL((k_rmsnorm_bwd<TX, TG, TO>), dim3(ttv_cdiv(rows, 4 * rpw)), dim3(256), 0, s, (const TX*)x, ldx, xr, (const TG*)dy,
                      lddy, dyr, gain, (TO*)dx, lddx, dxr, acc, dgain, rows, d, eps, rpw);
