@@ -335,6 +335,16 @@ int ttv_decoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
   GemmArgs a = {};
   a.dtype = dt; a.x = ws.pb; a.ldx = dm; a.w = w->proj_out_w; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.pa; a.ldy = pd;
   a.bias = w->proj_out_b;
+  // unpatchify inside the GEMM epilogue (8 consecutive output features = one 16-byte pixel row segment of a patch) when the
+  // shapes allow it: saves the [P, pd] round trip and the copy kernel.  TTV_FUSED_PATCH=0 keeps the two-kernel sequence.
+  static const bool use_fused_patch = !(getenv("TTV_FUSED_PATCH") && getenv("TTV_FUSED_PATCH")[0] == '0');
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (use_fused_patch && dt == TTV_BF16 && dm == 256 && d->patch_w == 8 && pow2(d->patch_t) && pow2(d->patch_h) &&
+      b->n_clips <= TTV_MAX_CLIPS_PER_LAUNCH && b->row_seq && pd % 64 == 0) {
+    a.clips = clips_out; a.n_clips = b->n_clips; a.clip_desc = b->clip_desc; a.patch_rows = b->patch_rows; a.row_seq = b->row_seq;
+    a.patch_t = d->patch_t; a.patch_h = d->patch_h; a.patch_w = d->patch_w;
+    return ttvk_gemm(EPI_STORE_PATCH, a, s);
+  }
   TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
   for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
     const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;

@@ -346,7 +346,6 @@ int ttvk_enc_tail(const void* x, int dtype, int ld, const int* rows_map, int row
 // Patch gather / scatter (utils.py:26-51).  A segment = the pw contiguous pixels of one (c, ipt, iph) image row
 // of a patch; the patch vector is stored in (c,pt,ph,pw) order so a segment is one 16-byte vector for pw = 8 bf16.
 // ------------------------------------------------------------------------------------------------
-struct ClipPtrs { void* p[TTV_MAX_CLIPS_PER_LAUNCH]; };
 
 template <typename T, bool SCATTER>
 __global__ __launch_bounds__(256) void k_patch_copy(ClipPtrs clips, const int* __restrict__ clip_desc, int clip0, int pt, int ph,

@@ -34,6 +34,16 @@ struct GemmDev {
   float eps;  // RMSNorm eps for the folded pre-norm (k256 kernel)
   int debug;  // diagnostics (ttv_debug_set): bit0 = skip epilogue stores
   const float* norm_gain;
+  // EPI_STORE_PATCH (decoder tail): GEMM row t is patch t; output goes into the clip tensors as patches
+  ClipPtrs clips;
+  const int* clip_desc; const int* patch_rows; const int* row_seq;
+  int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
+};
+
+// per-token part of a patch destination (EPI_STORE_PATCH), computed once per token tile
+struct PatchDst {
+  bf16_t* base;        // clip + first pixel of the patch (channel 0, ipt = iph = 0)
+  int thw, hw, w;      // channel / frame / image-row strides of that clip, in elements
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -51,7 +61,7 @@ __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
 // ------------------------------------------------------------------------------------------------
 template <int EPI, typename T, int NI, int NJ>
 __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)[NJ], const int (&feat)[NI],
-                                              f32x4 (&acc)[NI][NJ], f32x4 (&acc2)[NI][NJ], int kq) {
+                                              f32x4 (&acc)[NI][NJ], f32x4 (&acc2)[NI][NJ], int kq, const PatchDst* pd = nullptr) {
   if (p.debug & 1) {  // timing-only path: keep the values alive, store nothing
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -66,7 +76,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
 #pragma unroll
   for (int i = 0; i < NI; ++i) { fv[i] = feat[i] < p.N; fc[i] = fv[i] ? feat[i] : p.N - 4; }
 
-  if (EPI == EPI_STORE) {
+  if (EPI == EPI_STORE || EPI == EPI_STORE_PATCH) {
     if (p.bias) {
       f32x4 b[NI];
 #pragma unroll
@@ -158,7 +168,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
         recv.y = __shfl_xor(send.y, 16, 64);
         const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
         const int start = odd ? feat[i1] - 4 : feat[i0];
-        if (tv[j] && start + 8 <= p.N) *reinterpret_cast<uint4*>((T*)p.y + (size_t)tok[j] * p.ldy + start) = out;
+        if (EPI == EPI_STORE_PATCH) {
+          // 8 consecutive features = the pw = 8 pixels of one (c, ipt, iph) image row of the patch (utils.py:37-51, patch
+          // vector order (c, pt, ph, pw)): one 16-byte store into the clip
+          const int sg = start >> 3;
+          const int c = sg >> (p.pt_shift + p.ph_shift), ipt = (sg >> p.ph_shift) & ((1 << p.pt_shift) - 1), iph = sg & ((1 << p.ph_shift) - 1);
+          if (tv[j] && start + 8 <= p.N) *reinterpret_cast<uint4*>(pd[j].base + c * pd[j].thw + ipt * pd[j].hw + iph * pd[j].w) = out;
+        } else if (tv[j] && start + 8 <= p.N) {
+          *reinterpret_cast<uint4*>((T*)p.y + (size_t)tok[j] * p.ldy + start) = out;
+        }
       }
     }
   } else {
@@ -375,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   // EPI_QKV_ROPE: every rotary panel is one 64-wide head, so the (cos, sin) pairs this lane needs depend only on the
   // token: feature i*16 + kq*4 + {0..3} -> complex pairs i*8 + kq*2 + {0,1}.  Kept in registers per token tile.
   float2 rc[4][2], rs[4][2];
+  PatchDst pdst[2];
 
   bf16x8 a0[4], a1[4];
   GLDS_PANEL(it0 % n_panels, 0);
@@ -405,6 +424,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
             rc[i][j] = *reinterpret_cast<const float2*>(cs + i * 8);
             rs[i][j] = *reinterpret_cast<const float2*>(cs + 32 + i * 8);
           }
+        }
+      }
+      if (EPI == EPI_STORE_PATCH) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int t = tile * K256_TT + wave * 32 + j * 16 + l15;
+          t = t < p.M ? t : p.M - 1;
+          const int ci = p.row_seq[p.patch_rows[t]];
+          const int* ds = p.clip_desc + (size_t)ci * 8;
+          const int Tn = ds[0], H = ds[1], W = ds[2], gh = ds[4], gw = ds[5], pl = t - ds[6];
+          const int gwi = pl % gw, r = pl / gw, ghi = r % gh, gti = r / gh;
+          pdst[j].thw = Tn * H * W; pdst[j].hw = H * W; pdst[j].w = W;
+          pdst[j].base = reinterpret_cast<bf16_t*>(p.clips.p[ci - p.clip0]) +
+                         ((size_t)((gti << p.pt_shift) * H + (ghi << p.ph_shift)) * W + gwi * 8);
         }
       }
       if (PRENORM) {
@@ -491,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
       int feat[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) feat[i] = panel * FO + i * 16 + kq * 4;
-      epilogue_tile<EPI, bf16_t, 4, 2>(p, tok, feat, acc, acc, kq);
+      epilogue_tile<EPI, bf16_t, 4, 2>(p, tok, feat, acc, acc, kq, EPI == EPI_STORE_PATCH ? pdst : nullptr);
     }
   }
 #undef WROWIDX
@@ -820,8 +853,8 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     TTV_CHECK_LAUNCH("gemm_k256");
     return TTV_OK;
   }
-  if (prenorm) {
-    ttv_set_error("gemm: folded pre-norm needs the bf16 K=256 kernel");
+  if (prenorm || EPI == EPI_STORE_PATCH) {
+    ttv_set_error("gemm: folded pre-norm / patch scatter need the bf16 K=256 kernel");
     return TTV_ERR_UNSUPPORTED;
   }
   if (dtype == TTV_BF16) {
@@ -856,11 +889,22 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.eps = a.eps;
   d.debug = g_ttv_debug;
   d.norm_gain = a.norm_gain;
+  d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;
+  if (epi == EPI_STORE_PATCH) {
+    auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    TTV_CHECK_ARG(a.dtype == TTV_BF16 && a.K == 256 && a.patch_w == 8 && lg2(a.patch_t) >= 0 && lg2(a.patch_h) >= 0,
+                  "gemm: patch scatter needs bf16, K == 256, patch_w == 8 and power-of-two patch_t / patch_h");
+    TTV_CHECK_ARG(a.clips && a.n_clips > 0 && a.n_clips <= TTV_MAX_CLIPS_PER_LAUNCH && a.clip_desc && a.patch_rows && a.row_seq,
+                  "gemm: patch scatter needs clips (<= %d), clip_desc, patch_rows and row_seq", TTV_MAX_CLIPS_PER_LAUNCH);
+    for (int i = 0; i < a.n_clips; ++i) d.clips.p[i] = a.clips[i];
+    d.pt_shift = lg2(a.patch_t); d.ph_shift = lg2(a.patch_h);
+  }
   const bool pn = a.prenorm != 0;
-  const int kc = epi == EPI_STORE ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : epi == EPI_GEGLU ? TTV_KC_GEMM_GEGLU : TTV_KC_GEMM_RESID;
+  const int kc = (epi == EPI_STORE || epi == EPI_STORE_PATCH) ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : epi == EPI_GEGLU ? TTV_KC_GEMM_GEGLU : TTV_KC_GEMM_RESID;
   TtvProfScope prof(kc, s);
   switch (epi) {
     case EPI_STORE: return launch<EPI_STORE>(d, a.dtype, pn, s);
+    case EPI_STORE_PATCH: return launch<EPI_STORE_PATCH>(d, a.dtype, pn, s);
     case EPI_QKV_ROPE:
       // rotary ranges must be multiples of the largest feature tile (128) so that "rotate or not" is uniform per block
       TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 128 == 0 && a.rope_k_begin % 128 == 0 && a.rope_k_end % 128 == 0, "gemm: rotary ranges must be multiples of 128 columns");

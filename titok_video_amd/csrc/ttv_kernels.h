@@ -34,6 +34,7 @@ enum GemmEpilogue {
   EPI_RESID_F32,   // y = alpha*resid + acc, stored fp32                (KEEL pre-post-norm sum, transformer.py:141,144)
   EPI_RESID_NORM,  // y = RMSNorm(alpha*resid + acc) * norm_gain, stored in dtype (whole KEEL step, transformer.py:141-145);
                    // needs a kernel whose waves own full rows: bf16, K == 256, N == 256 (ttvk_gemm_supports_resid_norm)
+  EPI_STORE_PATCH, // y = acc + bias written straight into the clips as patches (blocks.py:173-176 + utils.py:37-51; bf16, K = 256)
 };
 
 struct GemmArgs {
@@ -51,7 +52,15 @@ struct GemmArgs {
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
   float eps;
+  // EPI_STORE_PATCH: row t of the GEMM is patch t (clip-major); its clip is row_seq[patch_rows[t]]
+  void* const* clips;              // HOST array of device pointers to the [C,T,H,W] outputs of clips clip0 .. clip0+n_clips-1
+  int n_clips;
+  const int* clip_desc;            // device [*,8], see ttv_patch_gather
+  const int* patch_rows;           // device [M]
+  const int* row_seq;              // device [L]
+  int patch_t, patch_h, patch_w;   // powers of two; patch_w * sizeof(bf16) == 16
 };
+struct ClipPtrs { void* p[TTV_MAX_CLIPS_PER_LAUNCH]; };
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 
