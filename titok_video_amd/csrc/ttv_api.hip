@@ -293,14 +293,25 @@ int ttv_encoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
   const int dm = d->width, dt = d->dtype, P = b->sum_patches;
   const int pd = d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
 
-  // patchify (utils.py:26-34) + proj_in (blocks.py:91-93)
-  for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
-    const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
-    TTV_TRY(ttvk_patch_copy(false, (void* const*)(clips + c0), b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.pa, pd, dt, b->max_patches_per_clip, s));
+  // patchify (utils.py:26-34) + proj_in (blocks.py:91-93); when the shapes allow it the GEMM reads its K = (c, pt, ph, pw)
+  // operand straight from the clips (16-byte pixel-row segments) instead of from a gathered [P, pd] copy
+  static const bool use_fused_patch = !(getenv("TTV_FUSED_PATCH") && getenv("TTV_FUSED_PATCH")[0] == '0');
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const bool gather = use_fused_patch && dt == TTV_BF16 && d->patch_w == 8 && pow2(d->patch_t) && pow2(d->patch_h) &&
+                      b->n_clips <= TTV_MAX_CLIPS_PER_LAUNCH && b->row_seq && pd % 64 == 0 && pd != 256;
+  if (!gather) {
+    for (int c0 = 0; c0 < b->n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+      const int n = b->n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? b->n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+      TTV_TRY(ttvk_patch_copy(false, (void* const*)(clips + c0), b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.pa, pd, dt, b->max_patches_per_clip, s));
+    }
   }
   GemmArgs a = {};
   a.dtype = dt; a.x = ws.pa; a.ldx = pd; a.w = w->proj_in_w; a.ldw = pd; a.M = P; a.N = dm; a.K = pd; a.y = ws.pb; a.ldy = dm;
   a.bias = w->proj_in_b; a.add_scalar = w->mask_token;
+  if (gather) {
+    a.gather = 1; a.clips = (void* const*)clips; a.n_clips = b->n_clips; a.clip_desc = b->clip_desc; a.patch_rows = b->patch_rows;
+    a.row_seq = b->row_seq; a.patch_t = d->patch_t; a.patch_h = d->patch_h; a.patch_w = d->patch_w;
+  }
   TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
   // x[patch rows] = ln_pre_p(patches + mask_token); x[latent rows] = ln_pre_t(mask_token * 1) (blocks.py:95-97)
   TTV_TRY(ttvk_rmsnorm(ws.pb, dt, dm, nullptr, ws.x, dt, dm, b->patch_rows, w->ln_pre_p, P, dm, d->eps, s));

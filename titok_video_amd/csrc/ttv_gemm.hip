@@ -200,7 +200,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int EPI>
+template <int EPI, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
   constexpr int FT = DUAL ? 64 : TF;  // output features per block
@@ -235,6 +235,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     wp0 = wrow(srow); wp1 = wrow(srow + 32); wp2 = wrow(srow + 64); wp3 = wrow(srow + 96);
     xp0 = xrow(srow); xp1 = xrow(srow + 32); xp2 = xrow(srow + 64); xp3 = xrow(srow + 96);
   }
+  // GATHER (encoder proj_in, blocks.py:91-93 + utils.py:26-34): GEMM row t is patch t and its K = (c, pt, ph, pw) vector is
+  // read straight from the clip: a 16-byte chunk = the pw = 8 pixels of one (c, ipt, iph) image row of the patch
+  PatchDst gx[4];
+  if (GATHER) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int t = tbase + srow + 32 * i;
+      t = t < p.M ? t : p.M - 1;
+      const int ci = p.row_seq[p.patch_rows[t]];
+      const int* ds = p.clip_desc + (size_t)ci * 8;
+      const int Tn = ds[0], H = ds[1], W = ds[2], gh = ds[4], gw = ds[5], pl = t - ds[6];
+      const int gwi = pl % gw, r = pl / gw, ghi = r % gh, gti = r / gh;
+      gx[i].thw = Tn * H * W; gx[i].hw = H * W; gx[i].w = W;
+      gx[i].base = reinterpret_cast<bf16_t*>(p.clips.p[ci - p.clip0]) + ((size_t)((gti << p.pt_shift) * H + (ghi << p.ph_shift)) * W + gwi * 8);
+    }
+  }
+#define GXPTR(i_, k0_)                                                                                          \
+  ({                                                                                                            \
+    const int sg__ = ((k0_) >> 3) + skc;                                                                        \
+    const int c__ = sg__ >> (p.pt_shift + p.ph_shift), ipt__ = (sg__ >> p.ph_shift) & ((1 << p.pt_shift) - 1);  \
+    const int iph__ = sg__ & ((1 << p.ph_shift) - 1);                                                           \
+    (const bf16_t*)(gx[i_].base + c__ * gx[i_].thw + ipt__ * gx[i_].hw + iph__ * gx[i_].w);                      \
+  })
   // swizzled LDS slot of (row, kc): row*8 + (kc ^ ((row>>1)&7))
   const int li0 = srow * 8 + (skc ^ ((srow >> 1) & 7));
   const int li1 = (srow + 32) * 8 + (skc ^ (((srow + 32) >> 1) & 7));
@@ -256,10 +279,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     sw1 = ok__ ? *reinterpret_cast<const uint4*>(wp1 + (k0)) : zero4;               \
     sw2 = ok__ ? *reinterpret_cast<const uint4*>(wp2 + (k0)) : zero4;               \
     sw3 = ok__ ? *reinterpret_cast<const uint4*>(wp3 + (k0)) : zero4;               \
-    sx0 = ok__ ? *reinterpret_cast<const uint4*>(xp0 + (k0)) : zero4;               \
-    sx1 = ok__ ? *reinterpret_cast<const uint4*>(xp1 + (k0)) : zero4;               \
-    sx2 = ok__ ? *reinterpret_cast<const uint4*>(xp2 + (k0)) : zero4;               \
-    sx3 = ok__ ? *reinterpret_cast<const uint4*>(xp3 + (k0)) : zero4;               \
+    sx0 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(0, k0) : xp0 + (k0)) : zero4; \
+    sx1 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(1, k0) : xp1 + (k0)) : zero4; \
+    sx2 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(2, k0) : xp2 + (k0)) : zero4; \
+    sx3 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(3, k0) : xp3 + (k0)) : zero4; \
   } while (0)
 #define LSTORE(buf)                                                                 \
   do {                                                                              \
@@ -296,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
   }
 #undef GLOAD
 #undef LSTORE
+#undef GXPTR
 
   int tok[4];
 #pragma unroll
@@ -890,10 +914,11 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.debug = g_ttv_debug;
   d.norm_gain = a.norm_gain;
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;
-  if (epi == EPI_STORE_PATCH) {
+  if (epi == EPI_STORE_PATCH || a.gather) {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
-    TTV_CHECK_ARG(a.dtype == TTV_BF16 && a.K == 256 && a.patch_w == 8 && lg2(a.patch_t) >= 0 && lg2(a.patch_h) >= 0,
-                  "gemm: patch scatter needs bf16, K == 256, patch_w == 8 and power-of-two patch_t / patch_h");
+    TTV_CHECK_ARG(a.dtype == TTV_BF16 && (a.gather || a.K == 256) && a.patch_w == 8 && lg2(a.patch_t) >= 0 && lg2(a.patch_h) >= 0,
+                  "gemm: patch gather/scatter needs bf16, patch_w == 8 and power-of-two patch_t / patch_h (scatter: K == 256)");
+    TTV_CHECK_ARG(!a.gather || (epi == EPI_STORE && a.K % 64 == 0 && a.K != 256), "gemm: patch gather is an EPI_STORE option of the general-K kernel");
     TTV_CHECK_ARG(a.clips && a.n_clips > 0 && a.n_clips <= TTV_MAX_CLIPS_PER_LAUNCH && a.clip_desc && a.patch_rows && a.row_seq,
                   "gemm: patch scatter needs clips (<= %d), clip_desc, patch_rows and row_seq", TTV_MAX_CLIPS_PER_LAUNCH);
     for (int i = 0; i < a.n_clips; ++i) d.clips.p[i] = a.clips[i];
@@ -903,7 +928,14 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   const int kc = (epi == EPI_STORE || epi == EPI_STORE_PATCH) ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : epi == EPI_GEGLU ? TTV_KC_GEMM_GEGLU : TTV_KC_GEMM_RESID;
   TtvProfScope prof(kc, s);
   switch (epi) {
-    case EPI_STORE: return launch<EPI_STORE>(d, a.dtype, pn, s);
+    case EPI_STORE:
+      if (a.gather) {
+        const int nf = ttv_cdiv(d.N, TF), nt = ttv_cdiv(d.M, TT);
+        hipLaunchKernelGGL((k_gemm_bf16<EPI_STORE, true>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+        TTV_CHECK_LAUNCH("gemm_gather");
+        return TTV_OK;
+      }
+      return launch<EPI_STORE>(d, a.dtype, pn, s);
     case EPI_STORE_PATCH: return launch<EPI_STORE_PATCH>(d, a.dtype, pn, s);
     case EPI_QKV_ROPE:
       // rotary ranges must be multiples of the largest feature tile (128) so that "rotate or not" is uniform per block

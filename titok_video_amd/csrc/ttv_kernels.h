@@ -52,7 +52,9 @@ struct GemmArgs {
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
   float eps;
-  // EPI_STORE_PATCH: row t of the GEMM is patch t (clip-major); its clip is row_seq[patch_rows[t]]
+  // EPI_STORE_PATCH (output side) / gather (EPI_STORE, input side): row t of the GEMM is patch t (clip-major); its clip is
+  // row_seq[patch_rows[t]]; x (gather) resp. y (scatter) is then unused
+  int gather;
   void* const* clips;              // HOST array of device pointers to the [C,T,H,W] outputs of clips clip0 .. clip0+n_clips-1
   int n_clips;
   const int* clip_desc;            // device [*,8], see ttv_patch_gather
