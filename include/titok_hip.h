@@ -174,6 +174,9 @@ typedef struct ttv_tower_weights {
   const void* proj_out_w;     /* enc: [token_size, d]; dec: [C*pt*ph*pw, d] rows in (c,pt,ph,pw) order */
   const void* proj_out_b;     /* enc: [token_size]; dec: [C*pt*ph*pw] same order */
   const ttv_layer_weights* layers;   /* HOST array [layers] */
+  /* optional (decoder, bf16, width 256): proj_out_w * ln_post gain[None,:]; when non-NULL the ln_post RMSNorm runs inside the
+   * proj_out GEMM (rows gathered through patch_rows, rstd from the register-resident row) */
+  const void* proj_out_pn;
 } ttv_tower_weights;
 
 /* Per-batch metadata, built on the host from Python ints (replaces the device-side bookkeeping and its

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.FsqParams) == 4 + 6 * 4 * _lib.TTV_MAX_FSQ
     assert C.sizeof(_lib.TowerDims) == 15 * 4
     assert C.sizeof(_lib.LayerWeights) == 11 * 8
-    assert C.sizeof(_lib.TowerWeights) == 9 * 8
+    assert C.sizeof(_lib.TowerWeights) == 10 * 8
     assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 8   # + blocks64, row_seq, n_blocks64 (padded)
     src = open(HEADER).read()
     for struct, cls in [("ttv_fsq_params", _lib.FsqParams), ("ttv_tower_dims", _lib.TowerDims),

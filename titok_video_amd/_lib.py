@@ -41,7 +41,7 @@ class LayerWeights(C.Structure):
 
 class TowerWeights(C.Structure):
     _fields_ = [("proj_in_w", vp), ("proj_in_b", vp), ("mask_token", vp), ("ln_pre_t", vp), ("ln_pre_p", vp),
-                ("ln_post", vp), ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerWeights))]
+                ("ln_post", vp), ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerWeights)), ("proj_out_pn", vp)]
 
 
 class Batch(C.Structure):

@@ -342,10 +342,16 @@ int ttv_decoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
   TTV_TRY(run_layers(d, w, b, ws, s));
 
   // patches = proj_out(ln_post(x[patch rows])) -> unpatchify (blocks.py:171-176)
-  TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, b->patch_rows, ws.pb, dt, dm, nullptr, w->ln_post, P, dm, d->eps, s));
   GemmArgs a = {};
-  a.dtype = dt; a.x = ws.pb; a.ldx = dm; a.w = w->proj_out_w; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.pa; a.ldy = pd;
+  a.dtype = dt; a.w = w->proj_out_w; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.pa; a.ldy = pd; a.ldx = dm;
   a.bias = w->proj_out_b;
+  if (dt == TTV_BF16 && dm == 256 && w->proj_out_pn && pd % 8 == 0) {
+    // ln_post folded into the GEMM: gain in the weight columns, rstd from the register-resident row, rows gathered in place
+    a.x = ws.x; a.x_rows = b->patch_rows; a.w = w->proj_out_pn; a.prenorm = 1; a.eps = d->eps;
+  } else {
+    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, b->patch_rows, ws.pb, dt, dm, nullptr, w->ln_post, P, dm, d->eps, s));
+    a.x = ws.pb;
+  }
   // unpatchify inside the GEMM epilogue (8 consecutive output features = one 16-byte pixel row segment of a patch) when the
   // shapes allow it: saves the [P, pd] round trip and the copy kernel.  TTV_FUSED_PATCH=0 keeps the two-kernel sequence.
   static const bool use_fused_patch = !(getenv("TTV_FUSED_PATCH") && getenv("TTV_FUSED_PATCH")[0] == '0');

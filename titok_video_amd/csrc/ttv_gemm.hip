@@ -37,6 +37,7 @@ struct GemmDev {
   // EPI_STORE_PATCH (decoder tail): GEMM row t is patch t; output goes into the clip tensors as patches
   ClipPtrs clips;
   const int* clip_desc; const int* patch_rows; const int* row_seq;
+  const int* x_rows;   // k256: GEMM row t reads x row x_rows[t] (NULL = identity)
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
 };
 
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
       for (int j = 0; j < 2; ++j) {
         int t = tile * K256_TT + wave * 32 + j * 16 + l15;
         t = t < p.M ? t : p.M - 1;
+        if (p.x_rows) t = p.x_rows[t];
         const bf16_t* xr = X + (size_t)t * p.ldx + kq * 8;
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
@@ -914,6 +916,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.debug = g_ttv_debug;
   d.norm_gain = a.norm_gain;
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;
+  d.x_rows = a.x_rows;
+  TTV_CHECK_ARG(!a.x_rows || (a.dtype == TTV_BF16 && a.K == 256 && a.N % 8 == 0 && epi != EPI_RESID_NORM), "gemm: x_rows needs the bf16 K=256 kernel");
   if (epi == EPI_STORE_PATCH || a.gather) {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
     TTV_CHECK_ARG(a.dtype == TTV_BF16 && (a.gather || a.K == 256) && a.patch_w == 8 && lg2(a.patch_t) >= 0 && lg2(a.patch_h) >= 0,

@@ -51,6 +51,7 @@ struct GemmArgs {
   int dtype;
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
+  const int* x_rows;               // optional (bf16, K == 256): GEMM row t reads x row x_rows[t]
   float eps;
   // EPI_STORE_PATCH (output side) / gather (EPI_STORE, input side): row t of the GEMM is patch t (clip-major); its clip is
   // row_seq[patch_rows[t]]; x (gather) resp. y (scatter) is then unused

@@ -265,7 +265,8 @@ class _WeightPack:
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
-            proj_out_w=lin(w_out), proj_out_b=lin(b_out), layers=self.layers)
+            proj_out_w=lin(w_out), proj_out_b=lin(b_out), layers=self.layers,
+            proj_out_pn=folded(w_out, tower.ln_post.weight) if tower.kind == _lib.TTV_DECODER else None)
         self.keep = keep
         self.kind, self.n_layers = tower.kind, n
         self._t = None
