@@ -96,21 +96,31 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
 
 /* Whole GEGLU sub-layer (transformer.py:47-56) + residual/KEEL step (:130, :144-145) in one kernel, bf16, width 256:
  * y = [RMSNorm](alpha*x + (gelu(xn@w12[I:]^T) * (xn@w12[:I]^T)) @ w3^T) [* post_gain], xn = RMSNorm(x)*norm_gain.
- * mlp_packed = ttv_mlp_pack(w12 * norm_gain[None,:], w3, out_proj): the per-panel LDS images the kernels stream (built once
- * per weight version, ttv_mlp_pack_bytes(inner) bytes; out_proj may be NULL when only ttv_mlp_fused is used);
- * post_gain NULL = plain residual (layer 0).  y may alias x.  TTV_ERR_UNSUPPORTED for other dtypes/widths. */
-int64_t ttv_mlp_pack_bytes(int inner);
-int ttv_mlp_pack(const void* w12_folded, const void* w3, const void* out_proj, int inner, int width, int dtype, void* mlp_packed,
-                 void* stream);
+ * mlp_packed = ttv_mlp_pack(w12 * norm_gain[None,:], w3, out_proj, next_qkv_folded, next_qkv_rows): the panel images the
+ * kernels stream by LDS-DMA (built once per weight version, ttv_mlp_pack_bytes(inner, next_qkv_rows) bytes; out_proj and
+ * next_qkv_folded may be NULL / 0 when the parts that use them are not); post_gain NULL = plain residual (layer 0).
+ * y may alias x.  TTV_ERR_UNSUPPORTED for other dtypes/widths. */
+int64_t ttv_mlp_pack_bytes(int inner, int next_qkv_rows);
+int ttv_mlp_pack(const void* w12_folded, const void* w3, const void* out_proj, const void* next_qkv_folded, int next_qkv_rows, int inner,
+                 int width, int dtype, void* mlp_packed, void* stream);
 int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
                   float eps, int M, int width, int dtype, void* stream);
+/* Optional last part of ttv_layer_tail_fused: the NEXT layer's attention input (transformer.py:86-98),
+ * qkv = rotary(RMSNorm(y) @ (to_qkv * pre_ln_gain)^T), rows = 2d+2g of the folded weight packed by ttv_mlp_pack. */
+typedef struct ttv_next_qkv {
+  void* qkv; int32_t ld;        /* [M, ld] output (q | gate | k | v) */
+  const float* rope_cs;         /* [M, 64] (cos | sin) */
+  int32_t rows;                 /* % 64 == 0 */
+  int32_t rope_q_end, rope_k_begin, rope_k_end;   /* rotary applies to features [0, q_end) and [k_begin, k_end); whole heads */
+} ttv_next_qkv;
 /* Everything of a transformer layer after the attention kernel (transformer.py:104, 129-130 / 141-145) in one kernel:
  *   x1 = [RMSNorm](attn_alpha*x + ao@out_proj^T) [* attn_post_gain]          (gain NULL = plain residual, layer 0)
  *   y  = [RMSNorm](ffd_alpha*x1 + GEGLU-feed-forward(x1)) [* ffd_post_gain]   (as ttv_mlp_fused)
+ *   next->qkv = the next layer's rotated qkv projection of y                  (next NULL = not computed)
  * y may alias x (it is also used to hand x1 from one wave to its partner inside a workgroup).  Same support as ttv_mlp_fused. */
 int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, float attn_alpha, const void* x, int ldx,
                          const void* mlp_packed, int inner, void* y, int ldy, const float* ffd_post_gain, float ffd_alpha, float eps,
-                         int M, int width, int dtype, void* stream);
+                         int M, int width, int dtype, const ttv_next_qkv* next, void* stream);
 
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
@@ -160,8 +170,10 @@ typedef struct ttv_layer_weights {
    * (w * gain[None,:]); when non-NULL the pre-norm runs inside the GEMM (rstd from the register-resident row) */
   const void* to_qkv_pn;
   const void* w12_pn;
-  /* optional (bf16, width 256): ttv_mlp_pack(w12_pn, w3, out_proj) - panel images of the fused layer-tail kernel */
+  /* optional (bf16, width 256): ttv_mlp_pack(w12_pn, w3, out_proj, NEXT layer's to_qkv_pn, rows) - panel images of the fused
+   * layer-tail kernel; mlp_pack_qkv_rows = rows of the next layer's to_qkv packed into it (0 = none, e.g. last layer) */
   const void* mlp_pack;
+  int32_t mlp_pack_qkv_rows;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {

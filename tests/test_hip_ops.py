@@ -247,9 +247,9 @@ def test_mlp_fused(M, keel, I):
     pg = 1 + 0.1 * torch.randn(d, generator=g)
     w12f = (w12.float() * ng[None, :]).to(torch.bfloat16)
     xd, w12d, w3d, pgd = x.to(DEV), w12f.to(DEV), w3.to(DEV), pg.to(DEV)
-    pack = torch.empty(L().ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
+    pack = torch.empty(L().ttv_mlp_pack_bytes(I, 0), dtype=torch.uint8, device=DEV)
     assert pack.numel() == (I // 32) * 48 * 1024 + 128 * 1024
-    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), None, I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
+    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), None, None, 0, I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
     alpha = 8.0 if keel else 1.0
     _lib.check(L().ttv_mlp_fused(xd.data_ptr(), d, pack.data_ptr(), I, xd.data_ptr(), d,
                                  pgd.data_ptr() if keel else None, alpha, 1e-5, M, d, _lib.TTV_BF16, S()), "mlp_fused")
@@ -267,25 +267,36 @@ def test_mlp_fused(M, keel, I):
 
 @pytest.mark.parametrize("M", [1, 100, 192, 1000, 20000, 40000])
 @pytest.mark.parametrize("keel", [True, False])
-def test_layer_tail_fused(M, keel):
-    """out_proj + residual/KEEL + GEGLU sub-layer + residual/KEEL in one kernel vs the op-by-op definition
-    (transformer.py:104,129-130 / 141-145, 47-56)."""
-    d, I = 256, 704
+@pytest.mark.parametrize("back", [False, True])
+def test_layer_tail_fused(M, keel, back):
+    """out_proj + residual/KEEL + GEGLU sub-layer + residual/KEEL (+ the next layer's pre_ln + to_qkv + rotary) in one kernel
+    vs the op-by-op definition (transformer.py:104,129-130 / 141-145, 47-56, 86-98)."""
+    import ctypes as C
+    d, I, gq = 256, 704, 128
+    nq = 2 * d + 2 * gq
     g = torch.Generator().manual_seed(M + 7)
     x = (torch.randn(M, d, generator=g) * 1.3).to(torch.bfloat16)
     ao = (torch.randn(M, d, generator=g)).to(torch.bfloat16)
     wo = (torch.randn(d, d, generator=g) * d ** -0.5).to(torch.bfloat16)
     w12 = (torch.randn(2 * I, d, generator=g) * d ** -0.5).to(torch.bfloat16)
     w3 = (torch.randn(d, I, generator=g) * I ** -0.5).to(torch.bfloat16)
-    ng, ag, pg = (1 + 0.1 * torch.randn(d, generator=g) for _ in range(3))
+    wq = (torch.randn(nq, d, generator=g) * d ** -0.5).to(torch.bfloat16)
+    ng, ag, pg, qg = (1 + 0.1 * torch.randn(d, generator=g) for _ in range(4))
+    ang = torch.rand(M, 32, generator=g) * 6.28
+    cs = torch.cat([ang.cos(), ang.sin()], 1).float()
     w12f = (w12.float() * ng[None, :]).to(torch.bfloat16)
-    xd, aod, w12d, w3d, wod, agd, pgd = (t.to(DEV) for t in (x, ao, w12f, w3, wo, ag, pg))
-    pack = torch.empty(L().ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
-    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), wod.data_ptr(), I, d, _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
+    wqf = (wq.float() * qg[None, :]).to(torch.bfloat16)
+    xd, aod, w12d, w3d, wod, wqd, agd, pgd, csd = (t.to(DEV) for t in (x, ao, w12f, w3, wo, wqf, ag, pg, cs))
+    rows = nq if back else 0
+    pack = torch.empty(L().ttv_mlp_pack_bytes(I, rows), dtype=torch.uint8, device=DEV)
+    _lib.check(L().ttv_mlp_pack(w12d.data_ptr(), w3d.data_ptr(), wod.data_ptr(), wqd.data_ptr() if back else None, rows, I, d,
+                                _lib.TTV_BF16, pack.data_ptr(), S()), "mlp_pack")
+    qkv = torch.zeros(M, nq, dtype=torch.bfloat16, device=DEV)
+    nx = _lib.NextQkv(qkv=qkv.data_ptr(), ld=nq, rope_cs=csd.data_ptr(), rows=nq, rope_q_end=d, rope_k_begin=2 * d, rope_k_end=2 * d + gq)
     alpha = 8.0 if keel else 1.0
     _lib.check(L().ttv_layer_tail_fused(aod.data_ptr(), d, agd.data_ptr() if keel else None, alpha, xd.data_ptr(), d, pack.data_ptr(), I,
-                                        xd.data_ptr(), d, pgd.data_ptr() if keel else None, alpha, 1e-5, M, d, _lib.TTV_BF16, S()),
-               "layer_tail_fused")
+                                        xd.data_ptr(), d, pgd.data_ptr() if keel else None, alpha, 1e-5, M, d, _lib.TTV_BF16,
+                                        C.byref(nx) if back else None, S()), "layer_tail_fused")
     y1 = alpha * x.double() + ao.double() @ wo.double().T
     x1 = y1 * torch.rsqrt(y1.pow(2).mean(-1, keepdim=True) + 1e-5) * ag.double() if keel else y1
     x1 = x1.to(torch.bfloat16).double()                                      # the kernel rounds x1 to bf16 (residual stream dtype)
@@ -295,6 +306,16 @@ def test_layer_tail_fused(M, keel):
     y = alpha * x1 + h @ w3.double().T
     ref = y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-5) * pg.double() if keel else y
     assert_close(xd.float(), ref, "bf16", scale=2.0)
+    if back:
+        x2 = xd.double().cpu()                                               # the projection reads the stored (bf16) rows
+        q = (x2 * torch.rsqrt(x2.pow(2).mean(-1, keepdim=True) + 1e-5)) @ wqf.double().T
+
+        def rot(t):                                                          # interleaved pairs, per 64-wide head
+            th = t.reshape(M, -1, 32, 2)
+            c, sn = cs[:, None, :32].double(), cs[:, None, 32:].double()
+            return torch.stack([th[..., 0] * c - th[..., 1] * sn, th[..., 0] * sn + th[..., 1] * c], -1).reshape(M, -1)
+        qref = torch.cat([rot(q[:, :d]), q[:, d:2 * d], rot(q[:, 2 * d:2 * d + gq]), q[:, 2 * d + gq:]], 1)
+        assert_close(qkv.float(), qref, "bf16", scale=2.0)
 
 
 # ---------------------------------------------------------------------------------------------- attention

@@ -34,9 +34,13 @@ class TowerDims(C.Structure):
                 ("pix_channels", i32), ("token_size", i32), ("eps", f32), ("alpha", f32)]
 
 
+class NextQkv(C.Structure):
+    _fields_ = [("qkv", vp), ("ld", i32), ("rope_cs", vp), ("rows", i32), ("rope_q_end", i32), ("rope_k_begin", i32), ("rope_k_end", i32)]
+
+
 class LayerWeights(C.Structure):
     _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
-                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("mlp_pack", vp)]
+                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("mlp_pack", vp), ("mlp_pack_qkv_rows", i32)]
 
 
 class TowerWeights(C.Structure):
@@ -87,10 +91,10 @@ SYMBOLS = {
                                       C.c_int, C.c_int, vp]),
     "ttv_linear_residual_norm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, f32, vp, f32, vp, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, vp]),
-    "ttv_mlp_pack_bytes": (C.c_int64, [C.c_int]),
-    "ttv_mlp_pack": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ttv_mlp_pack_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "ttv_mlp_pack": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_layer_tail_fused": (C.c_int, [vp, C.c_int, vp, f32, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int,
-                                       C.c_int, vp]),
+                                       C.c_int, vp, vp]),
     "ttv_mlp_fused": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,

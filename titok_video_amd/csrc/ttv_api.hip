@@ -86,25 +86,37 @@ static int check_dims(const ttv_tower_dims* d, const ttv_batch* b) {
 static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const TowerWs& ws, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
   const int nq = 2 * dm + 2 * g;
+  bool qkv_ready = false;   // the previous layer's tail kernel already produced this layer's rotated qkv
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
     // ---- attention sub-layer (transformer.py:85-104) ----
-    const bool fold_qkv = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn;
-    if (!fold_qkv) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
-    GemmArgs a = {};
-    a.dtype = dt;
-    a.prenorm = fold_qkv; a.eps = d->eps;
-    a.x = fold_qkv ? ws.x : ws.xn; a.ldx = dm; a.w = fold_qkv ? lw.to_qkv_pn : lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
-    a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
-    TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
+    if (!qkv_ready) {
+      const bool fold_qkv = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn;
+      if (!fold_qkv) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+      GemmArgs a = {};
+      a.dtype = dt;
+      a.prenorm = fold_qkv; a.eps = d->eps;
+      a.x = fold_qkv ? ws.x : ws.xn; a.ldx = dm; a.w = fold_qkv ? lw.to_qkv_pn : lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+      a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+      TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
+    }
+    qkv_ready = false;
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim, 1, dt, s));
-    // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h)
+    // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h).
+    // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
+    // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs
+    // of the tail kernel: 31 us against 35 us stand-alone in isolation, worse in the pipeline), so it is opt-in.
     static const bool use_fused_mlp = !(getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '0');
+    static const bool use_fused_qkv = getenv("TTV_FUSED_QKV") && getenv("TTV_FUSED_QKV")[0] == '1';
     if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.mlp_pack) {
       // one kernel for the rest of the layer: out_proj + residual/KEEL norm, then pre-norm + w12 + GEGLU + w3 +
-      // residual/KEEL norm, in place on x
+      // residual/KEEL norm, in place on x, and (when the pack carries it) the NEXT layer's pre_ln + to_qkv + rotary
+      MlpNextQkv nx = {};
+      const bool back = use_fused_qkv && i + 1 < d->layers && lw.mlp_pack_qkv_rows == nq && nq % 64 == 0 && dm % 64 == 0 && g % 64 == 0;
+      if (back) { nx.qkv = ws.qkv; nx.ld = nq; nx.rope_cs = b->rope_cs; nx.rows = nq; nx.rope_q_end = dm; nx.rope_k_begin = 2 * dm; nx.rope_k_end = 2 * dm + g; }
       TTV_TRY(ttvk_mlp_fused(ws.ao, dm, i == 0 ? nullptr : lw.attn_post_ln, i == 0 ? 1.f : d->alpha, ws.x, dm, lw.mlp_pack, d->inner,
-                             ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln, i == 0 ? 1.f : d->alpha, d->eps, L, s));
+                             ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln, i == 0 ? 1.f : d->alpha, d->eps, L, back ? &nx : nullptr, s));
+      qkv_ready = back;
       continue;
     }
     GemmArgs o = {};
@@ -225,14 +237,15 @@ int ttv_linear_residual_norm(const void* x, int ldx, const void* w, int ldw, con
   return ttvk_gemm(EPI_RESID_NORM, a, (hipStream_t)stream);
 }
 
-int64_t ttv_mlp_pack_bytes(int inner) { return ttvk_mlp_pack_bytes(inner); }
+int64_t ttv_mlp_pack_bytes(int inner, int next_qkv_rows) { return ttvk_mlp_pack_bytes(inner, next_qkv_rows); }
 
-int ttv_mlp_pack(const void* w12_folded, const void* w3, const void* out_proj, int inner, int width, int dtype, void* packed, void* stream) {
+int ttv_mlp_pack(const void* w12_folded, const void* w3, const void* out_proj, const void* next_qkv_folded, int next_qkv_rows, int inner,
+                 int width, int dtype, void* packed, void* stream) {
   if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
     ttv_set_error("mlp_pack: only bf16, width 256, inner %% 32 == 0");
     return TTV_ERR_UNSUPPORTED;
   }
-  return ttvk_mlp_pack(w12_folded, w3, out_proj, inner, packed, (hipStream_t)stream);
+  return ttvk_mlp_pack(w12_folded, w3, out_proj, next_qkv_folded, next_qkv_rows, inner, packed, (hipStream_t)stream);
 }
 
 int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, void* y, int ldy, const float* post_gain, float alpha,
@@ -241,19 +254,22 @@ int ttv_mlp_fused(const void* x, int ldx, const void* mlp_packed, int inner, voi
     ttv_set_error("mlp_fused: only bf16, width 256, inner %% 32 == 0");
     return TTV_ERR_UNSUPPORTED;
   }
-  return ttvk_mlp_fused(nullptr, 0, nullptr, 1.f, x, ldx, mlp_packed, inner, y, ldy, post_gain, alpha, eps, M, (hipStream_t)stream);
+  return ttvk_mlp_fused(nullptr, 0, nullptr, 1.f, x, ldx, mlp_packed, inner, y, ldy, post_gain, alpha, eps, M, nullptr, (hipStream_t)stream);
 }
 
 int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, float attn_alpha, const void* x, int ldx,
                          const void* mlp_packed, int inner, void* y, int ldy, const float* ffd_post_gain, float ffd_alpha, float eps,
-                         int M, int width, int dtype, void* stream) {
+                         int M, int width, int dtype, const ttv_next_qkv* next, void* stream) {
   if (!ttvk_mlp_fused_supported(dtype, width, inner)) {
     ttv_set_error("layer_tail_fused: only bf16, width 256, inner %% 32 == 0");
     return TTV_ERR_UNSUPPORTED;
   }
   TTV_CHECK_ARG(ao, "layer_tail_fused: null attention output");
+  MlpNextQkv nx = {};
+  if (next) { nx.qkv = next->qkv; nx.ld = next->ld; nx.rope_cs = next->rope_cs; nx.rows = next->rows; nx.rope_q_end = next->rope_q_end;
+              nx.rope_k_begin = next->rope_k_begin; nx.rope_k_end = next->rope_k_end; }
   return ttvk_mlp_fused(ao, ldao, attn_post_gain, attn_alpha, x, ldx, mlp_packed, inner, y, ldy, ffd_post_gain, ffd_alpha, eps, M,
-                        (hipStream_t)stream);
+                        next ? &nx : nullptr, (hipStream_t)stream);
 }
 
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,

@@ -73,10 +73,17 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
 
 // ---- ttv_mlp.hip ----
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner);
-int64_t ttvk_mlp_pack_bytes(int inner);
-int ttvk_mlp_pack(const void* w12_folded, const void* w3, const void* wo, int inner, void* packed, hipStream_t s);
+struct MlpNextQkv {     // optional fused back of the layer-tail kernel: the next layer's qkv projection + rotary
+  void* qkv; int ld;    // [M, ld] output, (q | gate | k | v)
+  const float* rope_cs; // [M, 64] (cos | sin)
+  int rows;             // rows of the folded to_qkv packed behind the feed-forward images (% 64 == 0)
+  int rope_q_end, rope_k_begin, rope_k_end;
+};
+int64_t ttvk_mlp_pack_bytes(int inner, int next_qkv_rows);
+int ttvk_mlp_pack(const void* w12_folded, const void* w3, const void* wo, const void* next_qkv_folded, int next_qkv_rows, int inner,
+                  void* packed, hipStream_t s);
 int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float front_alpha, const void* x, int ldx, const void* packed,
-                   int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, hipStream_t s);
+                   int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, const MlpNextQkv* nq, hipStream_t s);
 
 // ---- ttv_bwd.hip (backward kernels) ----
 int ttvk_l1_loss(void* const* recon, void* const* target, void* const* grad, const int* sizes, int n_clips, int total_clips, int dtype,

@@ -33,6 +33,11 @@ struct MlpDev {
   const bf16_t* ao; int ldao;
   const float* front_gain;
   float front_alpha;
+  // optional fused back (the NEXT layer's pre_ln + to_qkv + rotary, transformer.py:86-98): qkv <- rope(RMSNorm(y) @ Wqkv'^T),
+  // Wqkv' = to_qkv * pre_ln gain, packed as nqp 64-row panel images after the out_proj images
+  bf16_t* qkv; int ldq;
+  const float* rope_cs;
+  int nqp, rope_q_end, rope_k_begin, rope_k_end;
   int I;
   bf16_t* y; int ldy;
   const float* post_gain;
@@ -42,11 +47,24 @@ struct MlpDev {
 };
 
 // ---- weight packing: builds the per-panel LDS images once per weight version -------------------------------------
-__global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __restrict__ w3, const bf16_t* __restrict__ wo, int I,
-                           uint4* __restrict__ out) {
+__global__ void k_mlp_pack(const bf16_t* __restrict__ w12f, const bf16_t* __restrict__ w3, const bf16_t* __restrict__ wo,
+                           const bf16_t* __restrict__ wq, int nq_rows, int I, uint4* __restrict__ out) {
   const int np = I / 32;
+  const int nqp = (nq_rows + 63) / 64;
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS) return;
+  if (o >= np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + nqp * MLP_W12_CHUNKS) return;
+  if (o >= np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS) {
+    // next layer's to_qkv (pre-norm gain folded) as 64-row panel images, k order of the C-layout B fragments
+    const int c = o - np * MLP_PANEL_CHUNKS - MLP_WO_CHUNKS, qp = c / MLP_W12_CHUNKS, cc = c - qp * MLP_W12_CHUNKS;
+    const int r = cc >> 5, cp = cc & 31;
+    const int ch = (cp & 16) | ((cp & 15) ^ (r & 15));
+    int srow = qp * 64 + r;
+    srow = srow < nq_rows ? srow : nq_rows - 1;
+    const bf16_t* src = wq + (size_t)srow * 256 + (ch >> 2) * 32 + (ch & 3) * 4;
+    const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+    out[o] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return;
+  }
   if (o >= np * MLP_PANEL_CHUNKS) {
     // out_proj images: 4 panels of 64 rows, natural k order, same XOR swizzle
     const int c = o - np * MLP_PANEL_CHUNKS, wp = c / MLP_W12_CHUNKS, cc = c - wp * MLP_W12_CHUNKS;
@@ -106,7 +124,7 @@ __device__ __forceinline__ f32x4 cvt4(bf16x4 b) { return (f32x4){(float)b[0], (f
   } while (0)
 
 // One wave's share of one 64*NT-token tile: P1 of token tiles [P1F, P1F+T1), P2 of token tiles [P2F, P2F+NT-T1).
-template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL, bool FRONT>
+template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL, bool FRONT, bool BACK>
 __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3, uint4* hb, const float* gl, int tile, int wave, int lane,
                                          int& n_stamp) {
   constexpr int T2 = NT - T1;
@@ -396,6 +414,8 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   MLP_STAMP();
 
   // ---- epilogue of the P2 tiles: y = alpha*x + acc ; x_new = KEEL ? RMSNorm(y)*gain : y ----
+  bf16x8 xq[T2A][8];
+  float rstdq[T2A];
 #pragma unroll
   for (int j = 0; j < T2; ++j) {
     const int t = tok0 + 16 * (P2F + j);
@@ -428,6 +448,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     }
     const bool odd = kq & 1;
     const uint32_t yoff = ((uint32_t)tc * (uint32_t)p.ldy + (odd ? 16 + kq * 4 - 4 : kq * 4)) * 2u;   // + 64 bytes per ip
+    float ssq = 0.f;
 #pragma unroll
     for (int ip = 0; ip < 8; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
@@ -441,6 +462,15 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       const bf16x4 q0 = {(bf16_t)y0[0], (bf16_t)y0[1], (bf16_t)y0[2], (bf16_t)y0[3]};
       const bf16x4 q1 = {(bf16_t)y1[0], (bf16_t)y1[1], (bf16_t)y1[2], (bf16_t)y1[3]};
       const uint2 p0 = __builtin_bit_cast(uint2, q0), p1 = __builtin_bit_cast(uint2, q1);
+      if (BACK) {   // the rounded new rows in C layout are the B fragments of the next projection
+        xq[j][ip] = __builtin_bit_cast(bf16x8, make_uint4(p0.x, p0.y, p1.x, p1.y));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r0 = (float)q0[e], r1 = (float)q1[e];
+          ssq = fmaf(r0, r0, ssq);
+          ssq = fmaf(r1, r1, ssq);
+        }
+      }
       const uint2 send = odd ? p0 : p1;
       uint2 recv;
       recv.x = __shfl_xor(send.x, 16, 64);
@@ -448,13 +478,109 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       const uint4 ov = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
       if (tv && !(p.debug & 1)) *(__attribute__((address_space(1))) u32x4_t*)(gy + yoff + ip * 64) = (u32x4_t){ov.x, ov.y, ov.z, ov.w};
     }
+    if (BACK) {
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      rstdq[j] = 1.0f / sqrtf(ssq * (1.0f / 256.0f) + p.eps);
+    }
   }
   MLP_STAMP();
+
+  if (BACK) {
+    // ---- fused back: the next layer's qkv = rope(RMSNorm(x_new) Wqkv'^T) for the P2 tiles, straight from the registers
+    // the epilogue just produced; Wqkv' streams through the W12 buffers as nqp more panel images (all 8 waves copy).
+    // Explicitly-global row pointers + immediates, as everywhere in this kernel. ----
+#define GLDS_WQ(qp_, buf_)                                                                                         \
+  do {                                                                                                             \
+    const int src__ = np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + (qp_) * MLP_W12_CHUNKS + wave * 64;                  \
+    const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
+  } while (0)
+    GLDS_WQ(0, 0);
+    gchar* const gq = (gchar*)p.qkv;
+    gcchar* const grope = (gcchar*)p.rope_cs;
+    // rotary (cos, sin) of this lane's features: every rotary panel is one 64-wide head, so they depend on the token only
+    f32x2 rc[4][T2A], rs[4][T2A];
+    uint32_t qoff[T2A];
+    bool qv[T2A];
+#pragma unroll
+    for (int j = 0; j < T2; ++j) {
+      const int t = tok0 + 16 * (P2F + j);
+      qv[j] = t < p.M;
+      const int tc = qv[j] ? t : p.M - 1;
+      qoff[j] = ((uint32_t)tc * (uint32_t)p.ldq + kq * 4) * 2u;
+      gcchar* cs = grope + ((uint32_t)tc * 64u + kq * 2) * 4u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rc[i][j] = *(const __attribute__((address_space(1))) f32x2*)(cs + i * 32);
+        rs[i][j] = *(const __attribute__((address_space(1))) f32x2*)(cs + 128 + i * 32);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int qp = 0; qp < p.nqp; ++qp) {
+      if (qp + 1 < p.nqp) GLDS_WQ(qp + 1, (qp + 1) & 1);
+      const uint4* img = l12 + (qp & 1) * MLP_W12_CHUNKS;
+      f32x4 qa[4][T2A];
+      bf16x8 a[2][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[0][i] = MLP_LD12(img, i, 0);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        if (s8 + 1 < 8) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[(s8 + 1) & 1][i] = MLP_LD12(img, i, s8 + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < T2; ++j)
+            qa[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s8 & 1][i], xq[j][s8], s8 ? qa[i][j] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * T2A, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // wait + barrier BEFORE this panel's stores are issued: the vmcnt(0) then covers the next image's DMA and the
+      // previous panel's stores (a whole MFMA phase old), never the stores just issued
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      const int f_first = qp * 64;
+      const bool rot = f_first < p.rope_q_end || (f_first >= p.rope_k_begin && f_first < p.rope_k_end);
+#pragma unroll
+      for (int j = 0; j < T2; ++j) {
+        // 16-byte stores: lanes kq / kq^1 exchange one 4-feature group (as in the main epilogue), so a row gets 64-byte runs
+        const bool odd = kq & 1;
+        gchar* const qrow = gq + (qoff[j] - (uint32_t)(kq * 4) * 2u) + (uint32_t)(f_first + (odd ? 16 + kq * 4 - 4 : kq * 4)) * 2u;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+          uint2 pk[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int i = 2 * ip + u;
+            f32x4 v = qa[i][j] * rstdq[j];
+            if (rot)
+              v = (f32x4){v[0] * rc[i][j].x - v[1] * rs[i][j].x, v[0] * rs[i][j].x + v[1] * rc[i][j].x,
+                          v[2] * rc[i][j].y - v[3] * rs[i][j].y, v[2] * rs[i][j].y + v[3] * rc[i][j].y};
+            const bf16x4 q = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            pk[u] = __builtin_bit_cast(uint2, q);
+          }
+          const uint2 send = odd ? pk[0] : pk[1];
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 16, 64);
+          recv.y = __shfl_xor(send.y, 16, 64);
+          const u32x4_t ov = odd ? (u32x4_t){recv.x, recv.y, pk[1].x, pk[1].y} : (u32x4_t){pk[0].x, pk[0].y, recv.x, recv.y};
+          if (qv[j]) *(__attribute__((address_space(1))) u32x4_t*)(qrow + ip * 64) = ov;
+        }
+      }
+    }
+#undef GLDS_WQ
+    MLP_STAMP();
+  }
 #undef GLDS_W12
 #undef GLDS_W3
 }
 
-template <int NT, bool KEEL, bool FRONT>
+template <int NT, bool KEEL, bool FRONT, bool BACK>
 __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* const l12 = smem;                                 // [2][MLP_W12_CHUNKS]
@@ -471,8 +597,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
   constexpr int TA = NT - NT / 2;   // P1 tiles of the first wave of a pair (2 of 3, 1 of 2)
   int n_stamp = 0;
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL, FRONT>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
-    else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
+    if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
+    else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
   }
 }
 #undef MLP_LD12
@@ -481,23 +607,27 @@ __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
 
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner) { return dtype == TTV_BF16 && width == 256 && inner % 32 == 0 && inner > 0; }
 
-int64_t ttvk_mlp_pack_bytes(int inner) {
-  return inner > 0 && inner % 32 == 0 ? ((int64_t)(inner / 32) * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS) * 16 : 0;
+int64_t ttvk_mlp_pack_bytes(int inner, int next_qkv_rows) {
+  if (inner <= 0 || inner % 32 != 0 || next_qkv_rows < 0) return 0;
+  return ((int64_t)(inner / 32) * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + (int64_t)((next_qkv_rows + 63) / 64) * MLP_W12_CHUNKS) * 16;
 }
 
-int ttvk_mlp_pack(const void* w12_folded, const void* w3, const void* wo, int inner, void* packed, hipStream_t s) {
+int ttvk_mlp_pack(const void* w12_folded, const void* w3, const void* wo, const void* next_qkv_folded, int next_qkv_rows, int inner,
+                  void* packed, hipStream_t s) {
   TTV_CHECK_ARG(w12_folded && w3 && packed, "mlp_pack: null buffer");
   TTV_CHECK_ARG(inner > 0 && inner % 32 == 0, "mlp_pack: inner %% 32");
-  TTV_CHECK_ARG(((uintptr_t)w12_folded % 16 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)wo % 16 == 0), "mlp_pack: 16-byte alignment");
-  const int total = inner / 32 * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS;
+  TTV_CHECK_ARG((next_qkv_folded != nullptr) == (next_qkv_rows > 0), "mlp_pack: next_qkv weight and row count must come together");
+  TTV_CHECK_ARG(((uintptr_t)w12_folded % 16 == 0) && ((uintptr_t)packed % 16 == 0) && ((uintptr_t)wo % 16 == 0) &&
+                    ((uintptr_t)next_qkv_folded % 16 == 0), "mlp_pack: 16-byte alignment");
+  const int total = inner / 32 * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + (next_qkv_rows + 63) / 64 * MLP_W12_CHUNKS;
   hipLaunchKernelGGL(k_mlp_pack, dim3(ttv_cdiv(total, 256)), dim3(256), 0, s, (const bf16_t*)w12_folded, (const bf16_t*)w3,
-                     (const bf16_t*)wo, inner, (uint4*)packed);
+                     (const bf16_t*)wo, (const bf16_t*)next_qkv_folded, next_qkv_rows, inner, (uint4*)packed);
   TTV_CHECK_LAUNCH("mlp_pack");
   return TTV_OK;
 }
 
 int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float front_alpha, const void* x, int ldx, const void* packed,
-                   int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, hipStream_t s) {
+                   int inner, void* y, int ldy, const float* post_gain, float alpha, float eps, int M, const MlpNextQkv* nq, hipStream_t s) {
   if (M == 0) return TTV_OK;
   TTV_CHECK_ARG(x && packed && y, "mlp_fused: null buffer");
   TTV_CHECK_ARG(inner % 32 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!ao || ldao % 8 == 0), "mlp_fused: inner %% 32, leading dims %% 8");
@@ -507,6 +637,14 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
   d.x = (const bf16_t*)x; d.ldx = ldx; d.pack = (const uint4*)packed; d.I = inner;
   d.ao = (const bf16_t*)ao; d.ldao = ldao; d.front_gain = front_gain; d.front_alpha = front_alpha;
   d.y = (bf16_t*)y; d.ldy = ldy; d.post_gain = post_gain; d.alpha = alpha; d.eps = eps; d.M = M; d.debug = g_ttv_debug; d.stamps = g_ttv_stamps;
+  d.qkv = nullptr; d.ldq = 0; d.rope_cs = nullptr; d.nqp = 0; d.rope_q_end = d.rope_k_begin = d.rope_k_end = 0;
+  if (nq) {
+    TTV_CHECK_ARG(nq->qkv && nq->rope_cs && nq->rows > 0 && nq->rows % 64 == 0 && nq->ld >= nq->rows && nq->ld % 4 == 0 &&
+                      (uintptr_t)nq->qkv % 8 == 0, "mlp_fused: bad next-qkv arguments (rows %% 64, ld %% 4, 8-byte aligned)");
+    TTV_CHECK_ARG(nq->rope_q_end % 64 == 0 && nq->rope_k_begin % 64 == 0 && nq->rope_k_end % 64 == 0, "mlp_fused: rotary ranges must be whole heads");
+    d.qkv = (bf16_t*)nq->qkv; d.ldq = nq->ld; d.rope_cs = nq->rope_cs; d.nqp = nq->rows / 64;
+    d.rope_q_end = nq->rope_q_end; d.rope_k_begin = nq->rope_k_begin; d.rope_k_end = nq->rope_k_end;
+  }
   // tokens per wave pair (NT*16): tile size with the smallest (rounds over the 256 CUs) x (cost of one tile); a tile costs
   // about 16 + 19*NT us (measured: 54 us at NT = 2, 73 us at NT = 3), so small batches - the reference trains under a
   // 6144-token budget, configs/tiny.yaml:65 - take 64-token tiles on many CUs rather than a few CUs with fat tiles
@@ -523,12 +661,19 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
   const int grid = d.n_tiles < cus ? d.n_tiles : cus;
   const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4) + 2048;   // 96 KiB + 8 KiB per token tile + gains
   TtvProfScope prof(TTV_KC_GEMM_GEGLU, s);
-#define LAUNCH_MLP(NT_, KEEL_, FRONT_)                                                                              \
+#define LAUNCH_MLP(NT_, KEEL_, FRONT_, BACK_)                                                                       \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)k_mlp256<NT_, KEEL_, FRONT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_, FRONT_>), dim3(grid), dim3(512), smem, s, d);                          \
+    (void)hipFuncSetAttribute((const void*)k_mlp256<NT_, KEEL_, FRONT_, BACK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_, FRONT_, BACK_>), dim3(grid), dim3(512), smem, s, d);                   \
   } while (0)
-#define LAUNCH_MLP_F(NT_, KEEL_) do { if (ao) LAUNCH_MLP(NT_, KEEL_, true); else LAUNCH_MLP(NT_, KEEL_, false); } while (0)
+  // the fused back exists only together with the fused front (the layer-tail use): keeps the instantiation count down
+#define LAUNCH_MLP_F(NT_, KEEL_)                                                                                    \
+  do {                                                                                                              \
+    if (ao && nq) LAUNCH_MLP(NT_, KEEL_, true, true);                                                               \
+    else if (ao) LAUNCH_MLP(NT_, KEEL_, true, false);                                                               \
+    else LAUNCH_MLP(NT_, KEEL_, false, false);                                                                      \
+  } while (0)
+  TTV_CHECK_ARG(!nq || ao, "mlp_fused: the next-qkv part needs the out_proj front (ttv_layer_tail_fused)");
   if (post_gain) { if (nt == 3) LAUNCH_MLP_F(3, true); else if (nt == 2) LAUNCH_MLP_F(2, true); else LAUNCH_MLP_F(1, true); }
   else { if (nt == 3) LAUNCH_MLP_F(3, false); else if (nt == 2) LAUNCH_MLP_F(2, false); else LAUNCH_MLP_F(1, false); }
 #undef LAUNCH_MLP_F

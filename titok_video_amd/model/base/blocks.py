@@ -226,21 +226,30 @@ class _WeightPack:
             keep.append(t)
             return t.data_ptr()
 
-        def mlp_packed(w12, g, w3, wo):
-            """Per-panel LDS images of the fused layer-tail kernel (csrc/ttv_mlp.hip), built on the device by ttv_mlp_pack
-            from w12 * gain[None, :], w3 and out_proj."""
+        def folded_tensor(w, g):
+            t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
+            return t.to(dtype).contiguous()
+
+        def mlp_packed(w12, g, w3, wo, next_attn):
+            """Panel images of the fused layer-tail kernel (csrc/ttv_mlp.hip), built on the device by ttv_mlp_pack from
+            w12 * gain[None, :], w3, out_proj and - except for the last layer - the NEXT layer's to_qkv * pre_ln gain.
+            Returns (pointer, rows of the packed next-layer to_qkv)."""
             if not fold or w3.shape[1] % 32:
-                return None
-            w12f = (w12.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
-            w12f = w12f.to(dtype).contiguous()
+                return None, 0
+            w12f = folded_tensor(w12, g)
             w3c = w3.detach().to(device=device, dtype=dtype).contiguous()
             woc = wo.detach().to(device=device, dtype=dtype).contiguous()
+            wq, rows = None, 0
+            if next_attn is not None and next_attn.to_qkv.weight.shape[0] % 64 == 0:
+                wq = folded_tensor(next_attn.to_qkv.weight, next_attn.pre_ln.weight)
+                rows = int(wq.shape[0])
             inner = int(w3.shape[1])
-            out = torch.empty(_lib.lib().ttv_mlp_pack_bytes(inner), dtype=torch.uint8, device=device)
-            _lib.check(_lib.lib().ttv_mlp_pack(w12f.data_ptr(), w3c.data_ptr(), woc.data_ptr(), inner, tower.width, _lib.TTV_BF16,
-                                               out.data_ptr(), _lib.stream_ptr(device)), "mlp_pack")
-            keep.extend([w12f, w3c, woc, out])    # stream-ordered: inputs stay alive with the pack
-            return out.data_ptr()
+            out = torch.empty(_lib.lib().ttv_mlp_pack_bytes(inner, rows), dtype=torch.uint8, device=device)
+            _lib.check(_lib.lib().ttv_mlp_pack(w12f.data_ptr(), w3c.data_ptr(), woc.data_ptr(), wq.data_ptr() if wq is not None else None,
+                                               rows, inner, tower.width, _lib.TTV_BF16, out.data_ptr(), _lib.stream_ptr(device)),
+                       "mlp_pack")
+            keep.extend([w12f, w3c, woc, wq, out])    # stream-ordered: inputs stay alive with the pack
+            return out.data_ptr(), rows
 
         perm = tower._patch_perm().to(device)
         if tower.kind == _lib.TTV_ENCODER:
@@ -255,13 +264,15 @@ class _WeightPack:
         self.layers = (_lib.LayerWeights * n)()
         for i in range(n):
             a, f = ml.attn_layer[i], ml.ffd_layer[i]
+            pack_ptr, pack_rows = mlp_packed(f.w12.weight, f.norm.weight, f.w3.weight, a.out_proj.weight,
+                                             ml.attn_layer[i + 1] if i + 1 < n else None)
             self.layers[i] = _lib.LayerWeights(
                 pre_ln=gain(a.pre_ln.weight), to_qkv=lin(a.to_qkv.weight), out_proj=lin(a.out_proj.weight),
                 ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
                 ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
                 to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight), w12_pn=folded(f.w12.weight, f.norm.weight),
-                mlp_pack=mlp_packed(f.w12.weight, f.norm.weight, f.w3.weight, a.out_proj.weight))
+                mlp_pack=pack_ptr, mlp_pack_qkv_rows=pack_rows)
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),

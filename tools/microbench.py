@@ -73,12 +73,15 @@ for dbg in ([0, 1] if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
            2.0 * L * d * d, L * d * (2 + 2 + 4))
     timeit("residual+norm fused K256 N256 (rownorm)", lambda: lib.ttv_linear_residual_norm(x.data_ptr(), d, wo.data_ptr(), d, yb.data_ptr(), d, 8.0, gain.data_ptr(), 1e-5, yb.data_ptr(), d, L, d, d, 0, S),
            2.0 * L * d * d, L * d * 6)
-    mpack = torch.empty(lib.ttv_mlp_pack_bytes(I), dtype=torch.uint8, device=DEV)
-    lib.ttv_mlp_pack(w12.data_ptr(), w3.data_ptr(), wo.data_ptr(), I, d, 0, mpack.data_ptr(), S)
+    mpack = torch.empty(lib.ttv_mlp_pack_bytes(I, 768), dtype=torch.uint8, device=DEV)
+    lib.ttv_mlp_pack(w12.data_ptr(), w3.data_ptr(), wo.data_ptr(), wqkv.data_ptr(), 768, I, d, 0, mpack.data_ptr(), S)
     timeit("fused MLP (w12+geglu+w3+keel+norm)", lambda: lib.ttv_mlp_fused(x.data_ptr(), d, mpack.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, S),
            2.0 * L * d * 3 * I, L * d * 4)
-    timeit("layer tail fused (out_proj+keel+mlp+keel)", lambda: lib.ttv_layer_tail_fused(ao.data_ptr(), d, gain.data_ptr(), 8.0, x.data_ptr(), d, mpack.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, S),
+    timeit("layer tail fused (out_proj+keel+mlp+keel)", lambda: lib.ttv_layer_tail_fused(ao.data_ptr(), d, gain.data_ptr(), 8.0, x.data_ptr(), d, mpack.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, None, S),
            2.0 * L * d * (3 * I + d), L * d * 6)
+    nxq = _lib.NextQkv(qkv=qkv.data_ptr(), ld=768, rope_cs=plan.rope_cs.data_ptr(), rows=768, rope_q_end=256, rope_k_begin=512, rope_k_end=640)
+    timeit("layer tail fused + next qkv/rope", lambda: lib.ttv_layer_tail_fused(ao.data_ptr(), d, gain.data_ptr(), 8.0, x.data_ptr(), d, mpack.data_ptr(), I, yb.data_ptr(), d, gain.data_ptr(), 8.0, 1e-5, L, d, 0, C.byref(nxq), S),
+           2.0 * L * d * (3 * I + d + 768), L * d * 6 + L * 768 * 2)
     timeit("residual+norm fused K704 N256 (rowtile)", lambda: lib.ttv_linear_residual_norm(h.data_ptr(), I, w3.data_ptr(), I, yb.data_ptr(), d, 8.0, gain.data_ptr(), 1e-5, yb.data_ptr(), d, L, d, I, 0, S),
            2.0 * L * I * d, L * (I * 2 + d * 4))
     if QUICK:
