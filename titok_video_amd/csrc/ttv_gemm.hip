@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   constexpr int FO = DUAL ? 32 : 64;  // output features per panel
   __shared__ uint4 wl[2][K256_ROWS * 32];  // [buffer][row*32 + swizzled 16-byte chunk], 2 x 32 KiB
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations are SGPR operands
   const int l15 = lane & 15, kq = lane >> 4;
   // consecutive logical blocks share token tiles; keep them on one XCD (same L2) under round-robin dispatch
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -386,14 +387,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
     int wr__ = DUAL ? ((row_) < 32 ? (panel_) * 32 + (row_) : p.N + (panel_) * 32 + ((row_) - 32)) : (panel_) * 64 + (row_); \
     wr__ < p.w_rows ? wr__ : p.w_rows - 1;                                                                   \
   })
+  // issued as asm (scalar base + per-lane byte offset): with the builtin form hipcc sees an LDS write in flight and turns every
+  // lgkmcnt wait of the main loop into lgkmcnt(0), exposing a fragment-read latency every other k-step
+  const uint32_t wl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&wl[0][0];
 #define GLDS_PANEL(panel_, buf_)                                                                             \
   do {                                                                                                       \
     _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) {                                                    \
       const int r0__ = wave * 16 + 2 * i__, row__ = r0__ + g_half;                                           \
       const int ch__ = (g_c & 16) | ((g_c & 15) ^ (row__ & 15));                                             \
-      const bf16_t* src__ = W + (size_t)WROWIDX(panel_, row__) * p.ldw + ch__ * 8;                           \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src__,                 \
-                                       (__attribute__((address_space(3))) void*)&wl[buf_][r0__ * 32], 16, 0, 0); \
+      const uint32_t voff__ = ((uint32_t)WROWIDX(panel_, row__) * (uint32_t)p.ldw + ch__ * 8) * 2u;          \
+      const uint32_t dst__ = wl_lds + ((buf_) * (K256_ROWS * 32) + r0__ * 32) * 16;                          \
+      unsigned keep__;                                                                                       \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep__) : "v"(voff__), "s"(p.w), "s"(dst__) : "memory");                             \
     }                                                                                                        \
   } while (0)
   // A fragments of k-step s8 (4 m-tiles) from panel buffer buf_
@@ -420,11 +426,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   float2 rc[4][2], rs[4][2];
   PatchDst pdst[2];
 
-  bf16x8 a0[4], a1[4];
+  bf16x8 af[2][4];
   GLDS_PANEL(it0 % n_panels, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
-  LOADA(a0, 0, 0);
+  LOADA(af[0], 0, 0);
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
     const int tile = it / n_panels, panel = it - tile * n_panels;
@@ -494,27 +500,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
       for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // A fragments double-buffered in registers: the reads of k-step s+1 are issued before the 8 MFMAs of k-step s
 #pragma unroll
-    for (int s8 = 0; s8 < 8; s8 += 2) {
-      LOADA(a1, buf, s8 + 1);
-      MFMA8(a0, s8);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the 4 fragment reads first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs that cover their latency
-      __builtin_amdgcn_sched_barrier(0);
-      if (s8 + 2 < 8) {
-        LOADA(a0, buf, s8 + 2);
-        MFMA8(a1, s8 + 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-      } else {
-        MFMA8(a1, s8 + 1);
+    for (int s8 = 0; s8 < 8; ++s8) {
+      if (s8 + 1 < 8) {
+        const int ch = (s8 + 1) * 4 + kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int arow = i * 16 + l15;
+          af[(s8 + 1) & 1][i] = __builtin_bit_cast(bf16x8, wl[buf][arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s8 & 1][i], bfr[j][s8], acc[i][j], 0, 0, 0);
+      if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ONE barrier per item, before the epilogue: next panel landed (vmcnt(0)) and every wave is done with this one;
     // the waves then run their epilogues unsynchronised, with the first fragments of the next item already requested
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next panel is in LDS
     __syncthreads();
-    if (it + 1 < it1) LOADA(a0, buf ^ 1, 0);
+    if (it + 1 < it1) LOADA(af[0], buf ^ 1, 0);
 
     int tok[2];
 #pragma unroll
