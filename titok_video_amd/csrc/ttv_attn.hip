@@ -110,17 +110,27 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
     const char* vt_lds = vbase_lds + buf * (KB * 128);
 
     // ---- S^T = K Q^T (64 keys x 32 queries per wave) ----
+    // all 8 K fragments of the tile are requested before the first MFMA (left to itself the compiler issues each read right
+    // in front of its MFMA and waits for it: 8 exposed LDS latencies per tile)
     f32x16 s_acc[2];
+    {
+      bf16x8 kf[2][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kt_lds + koff0 + t * 4096);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kt_lds + koff1 + t * 4096);
-      const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kt_lds + koff2 + t * 4096);
-      const bf16x8 k3 = *reinterpret_cast<const bf16x8*>(kt_lds + koff3 + t * 4096);
-      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], zero16, 0, 0, 0);
-      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], s_acc[t], 0, 0, 0);
-      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[2], s_acc[t], 0, 0, 0);
-      s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, qf[3], s_acc[t], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) {
+        kf[t][0] = *reinterpret_cast<const bf16x8*>(kt_lds + koff0 + t * 4096);
+        kf[t][1] = *reinterpret_cast<const bf16x8*>(kt_lds + koff1 + t * 4096);
+        kf[t][2] = *reinterpret_cast<const bf16x8*>(kt_lds + koff2 + t * 4096);
+        kf[t][3] = *reinterpret_cast<const bf16x8*>(kt_lds + koff3 + t * 4096);
+      }
+      // the two score tiles interleaved: consecutive MFMAs are independent, each chain of 4 has a tile's worth of slack
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], ks ? s_acc[t] : zero16, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // mask keys past the end of the sequence (last tile only)
     if (kt * KB + KB > S) {
@@ -169,20 +179,30 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
 #undef PFRAG
 
     // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const char* vb = vt_lds + (dt == 0 ? voff_d0 : voff_d1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const bf16x4 lo = lds_read_tr16(vb + t * 4096 + sp * 2048);
-          const bf16x4 hi = lds_read_tr16(vb + t * 4096 + sp * 2048 + 1024);
-          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const bf16x8 pfr = t == 0 ? (sp == 0 ? pf00 : pf01) : (sp == 0 ? pf10 : pf11);
-          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfr, o_acc[dt], 0, 0, 0);
-        }
+    // the V^T fragments of a d-half are requested together, one half ahead of the MFMAs that use them
+#define VFRAG(dt_, t_, sp_)                                                                                        \
+  ({                                                                                                               \
+    const char* vb__ = vt_lds + ((dt_) == 0 ? voff_d0 : voff_d1) + (t_) * 4096 + (sp_) * 2048;                     \
+    const bf16x4 lo__ = lds_read_tr16(vb__), hi__ = lds_read_tr16(vb__ + 1024);                                    \
+    (bf16x8){lo__[0], lo__[1], lo__[2], lo__[3], hi__[0], hi__[1], hi__[2], hi__[3]};                              \
+  })
+    {
+      bf16x8 vf0[4], vf1[4];
+      vf0[0] = VFRAG(0, 0, 0); vf0[1] = VFRAG(0, 0, 1); vf0[2] = VFRAG(0, 1, 0); vf0[3] = VFRAG(0, 1, 1);
+      vf1[0] = VFRAG(1, 0, 0); vf1[1] = VFRAG(1, 0, 1); vf1[2] = VFRAG(1, 1, 0); vf1[3] = VFRAG(1, 1, 1);
+      o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[0], pf00, o_acc[0], 0, 0, 0);
+      o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[0], pf00, o_acc[1], 0, 0, 0);
+      o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[1], pf01, o_acc[0], 0, 0, 0);
+      o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[1], pf01, o_acc[1], 0, 0, 0);
+      o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[2], pf10, o_acc[0], 0, 0, 0);
+      o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[2], pf10, o_acc[1], 0, 0, 0);
+      o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[3], pf11, o_acc[0], 0, 0, 0);
+      o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[3], pf11, o_acc[1], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef VFRAG
 
     if (kt + 1 < nkt) LSTORE(buf ^ 1);
     __syncthreads();
