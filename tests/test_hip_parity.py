@@ -173,6 +173,24 @@ def test_packing_invariance(dtype):
             assert torch.equal(r1[0], recon[i])
 
 
+def test_more_clips_than_one_pointer_table_bf16():
+    """Batches of more than TTV_MAX_CLIPS_PER_LAUNCH (64) clips take the stand-alone patch copy / ln_post kernels instead of
+    the GEMM-fused gather / scatter: same results up to bf16 rounding of the folded gain."""
+    model = build(torch.bfloat16)
+    n = 70
+    shapes = [(4, 16, 16)] * n
+    counts = [2] * n
+    clips = synthetic_clips(shapes, seed=5, dtype=torch.bfloat16, device=DEV)
+    with torch.no_grad():
+        recon, out = model(clips, counts)                       # 70 clips: unfused patch paths
+        ra, oa = model(clips[:35], counts[:35])                 # <= 64 clips: fused paths
+        rb, ob = model(clips[35:], counts[35:])
+    idx2 = torch.cat([oa["indices"], ob["indices"]])
+    assert torch.equal(out["indices"], idx2)                    # the encoder side differs only by where the operand is read from
+    worst = max(float((x.float() - y.float()).abs().max()) for x, y in zip(recon, list(ra) + list(rb)))
+    assert worst < 0.08, worst
+
+
 def test_discriminator_style_encoder_call():
     """ReconstructionLoss builds TiTokEncoder(out_channels=1) and calls it with K=4 register tokens (loss_module.py:43-48,96-101)."""
     enc = TiTokEncoder(model_size="tiny", patch_size=(4, 8, 8), in_channels=3, out_channels=1)
