@@ -280,8 +280,13 @@ int ttv_decoder_backward(const ttv_tower_dims* dims, const ttv_tower_weights* w,
 int ttv_fsq_backward(const ttv_fsq_params* p, const float* z, const void* dcodes, int dcodes_dtype, float* dz, int rows, void* stream);
 
 /* Single backward ops, exported for parity tests. */
-/* dW[N,K] (fp32, accumulated) += dY[L,N]^T X[L,K]  (weight gradient of y = x w^T). */
-int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype, void* stream);
+/* dW[N,K] (fp32, accumulated) += dY[L,N]^T X[L,K]  (weight gradient of y = x w^T; what autograd computes for the
+ * nn.Linear weights of base/blocks.py:70-84,147-148).  The token range is split over blocks; with a workspace of
+ * ttv_linear_wgrad_workspace_bytes(L, N, K) bytes the split partial tiles are summed in a fixed order (bit-reproducible),
+ * with workspace == NULL (workspace_bytes == 0) they are accumulated with fp32 atomics. */
+int64_t ttv_linear_wgrad_workspace_bytes(int L, int N, int K);
+int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 /* RMSNorm backward: dx (dtype), dgain fp32 [width] (accumulated; may be NULL). */
 int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const float* gain, void* dx, int lddx, float* dgain, int rows,
                          int width, float eps, int dtype, void* stream);

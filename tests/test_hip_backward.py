@@ -47,18 +47,28 @@ def config():
 
 # ---------------------------------------------------------------------------------------------- single kernels
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
-@pytest.mark.parametrize("shape", [(1000, 256, 768), (333, 768, 256), (2500, 1408, 256), (130, 256, 704)])
-def test_wgrad(dt, shape):
+@pytest.mark.parametrize("shape", [(1000, 256, 768), (333, 768, 256), (2500, 1408, 256), (130, 256, 704), (36864, 768, 256), (64, 256, 256),
+                                   (70, 8, 264), (4097, 136, 120)])
+@pytest.mark.parametrize("workspace", [False, True])
+def test_wgrad(dt, shape, workspace):
     Lr, N, K = shape
     g = torch.Generator().manual_seed(Lr)
     dy = torch.randn(Lr, N, generator=g).to(DT[dt])
     x = torch.randn(Lr, K, generator=g).to(DT[dt])
-    dw = torch.zeros(N, K, device=DEV)
     dyd, xd = dy.to(DEV), x.to(DEV)
-    for _ in range(2):     # accumulates
-        _lib.check(L().ttv_linear_wgrad(dyd.data_ptr(), N, xd.data_ptr(), K, dw.data_ptr(), K, Lr, N, K, _lib.dtype_code(DT[dt]), S()), "wgrad")
+    nbytes = int(L().ttv_linear_wgrad_workspace_bytes(Lr, N, K)) if workspace else 0
+    ws = torch.full((max(nbytes, 4) // 4,), float("nan"), device=DEV)   # stale partials must never leak into dW
+    outs = []
+    for _ in range(2):     # two independent runs: with a workspace the split sum has a fixed order
+        dw = torch.zeros(N, K, device=DEV)
+        for _ in range(2):     # accumulates
+            _lib.check(L().ttv_linear_wgrad(dyd.data_ptr(), N, xd.data_ptr(), K, dw.data_ptr(), K, Lr, N, K, _lib.dtype_code(DT[dt]),
+                                            ws.data_ptr() if workspace else None, nbytes, S()), "wgrad")
+        outs.append(dw)
     ref = 2 * (dy.double().T @ x.double())
-    assert rel(dw, ref) < (2e-3 if dt == "bf16" else 2e-5)
+    assert rel(outs[0], ref) < (2e-3 if dt == "bf16" else 2e-5)
+    if workspace and dt == "bf16":     # the fp32 checking kernel accumulates with atomics
+        assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])

@@ -454,6 +454,200 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const bf16_t* __restrict__ d
     }
 }
 
+// 128 x 128 outputs per block (64 x 64 per wave: every transposed fragment read feeds four MFMAs), 64 tokens per step.
+// Tiles are staged by LDS-DMA into two stages of [64 tokens][128 cols] bf16 (256-byte rows = one bank row).  A transposed
+// read addresses, per 32-lane half, 8 token rows x 32 bytes in the same columns: the 32-byte column pair of row r is stored
+// at pair index ^ g(r), g(r) = (r & 3) | ((r >> 3) & 1) << 2, so the 8 rows of a half land on 8 different pairs (conflict-free).
+// The DMA writes LDS linearly per lane, so the swizzle is applied on the global side (lane fetches the chunk that belongs at
+// its LDS position).  Columns past N / K fetch a valid chunk instead (they only feed outputs that are never written); token
+// rows past the range are re-fetched from the last valid row and zeroed in LDS before the barrier.
+#define WG_STAGE_BYTES 32768
+#define WG_OP_BYTES 16384
+//
+// PARTIAL: instead of fp32 atomics (which retire ~1 element per clock per L2 channel and dominate short token ranges) every
+// block stores its 128 x 128 fp32 tile in fragment order (each wave instruction writes 1 KB contiguous) to
+// part[(tile * splits + split)][wave][i][j][lane][4]; k_wgrad_reduce sums the splits in a fixed order and adds into dW, so
+// the result is also bit-reproducible from run to run.
+template <bool PARTIAL>
+__global__ __launch_bounds__(256, 2) void k_wgrad128_bf16(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                          float* __restrict__ dw, int lddw, int L, int N, int K, int tokens_per_block,
+                                                          float* __restrict__ part, int tiles_n, int tiles_k, int splits) {
+  __shared__ __attribute__((aligned(16))) char wg[2 * WG_STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const int l15 = lane & 15, kq = lane >> 4, tq = l15 >> 2, tp = l15 & 3;
+  // XCD-aware work mapping: consecutive block ids go round-robin over the 8 XCDs (each with its own L2), so the token range
+  // (split) is taken from id % 8 and the tile from id / 8: all tiles of one split run on ONE XCD at about the same time and the
+  // dY / X rows they share are fetched from HBM / MALL once and re-read from that L2 (splits is a multiple of 8 when > 8).
+  const int tiles = tiles_n * tiles_k;
+  int split, tile;
+  if (splits >= 8) {
+    const int slot = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) + 8 * (slot / tiles);
+    tile = slot % tiles;
+  } else {
+    split = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  if (split >= splits) return;
+  const int n0 = (tile % tiles_n) * 128, k0 = (tile / tiles_n) * 128;
+  const int t_begin = split * tokens_per_block;
+  const int t_end = min(L, t_begin + tokens_per_block);
+  if (!PARTIAL && t_begin >= t_end) return;
+  const uint32_t wg_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&wg[0];
+
+  // DMA lane mapping: instruction i of wave w covers tile rows 4*(4w+i) .. +3 (lane>>4 picks the row), LDS chunk = lane&15
+  uint32_t voy[4], vox[4];
+  int cy[4], cx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = kq | ((i >> 1) << 2);
+    const int ch = l15 ^ (g << 1);
+    cy[i] = (n0 + ch * 8 < N) ? ch * 8 : 0;
+    cx[i] = (k0 + ch * 8 < K) ? ch * 8 : 0;
+    const int r = (wave * 4 + i) * 4 + kq;
+    voy[i] = (uint32_t)(r * lddy + cy[i]) * 2u;
+    vox[i] = (uint32_t)(r * ldx + cx[i]) * 2u;
+  }
+#define WG_DMA(voff_, base_, dst_)                                                                              \
+  do {                                                                                                          \
+    unsigned keep__;                                                                                            \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                \
+  } while (0)
+#define WG_STAGE(t0_, buf_)                                                                                     \
+  do {                                                                                                          \
+    const bf16_t* by__ = dy + (size_t)(t0_) * lddy + n0;                                                        \
+    const bf16_t* bx__ = x + (size_t)(t0_) * ldx + k0;                                                          \
+    const int last__ = t_end - 1 - (t0_);                                                                       \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                       \
+      const uint32_t dst__ = wg_lds + (buf_) * WG_STAGE_BYTES + (wave * 4 + i__) * 1024;                        \
+      uint32_t vy__ = voy[i__], vx__ = vox[i__];                                                                \
+      if (last__ < 63) {                                                                                        \
+        const int r__ = min((wave * 4 + i__) * 4 + kq, last__);                                                 \
+        vy__ = (uint32_t)(r__ * lddy + cy[i__]) * 2u;                                                           \
+        vx__ = (uint32_t)(r__ * ldx + cx[i__]) * 2u;                                                            \
+      }                                                                                                         \
+      WG_DMA(vy__, by__, dst__);                                                                                \
+      WG_DMA(vx__, bx__, dst__ + WG_OP_BYTES);                                                                  \
+    }                                                                                                           \
+  } while (0)
+
+  // fragment read offsets: token row = 32*st + 8*kq + tq (+4 for the upper half of the 8 tokens), g is the same for all of them
+  const int g2 = tq | ((kq & 1) << 2);
+  const int rowoff = (kq * 8 + tq) * 256 + (tp & 1) * 8;
+  int offa[4], offb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    offa[i] = rowoff + (((wn * 8 + i * 2 + (tp >> 1)) ^ (g2 << 1)) << 4);
+    offb[i] = rowoff + (((wk * 8 + i * 2 + (tp >> 1)) ^ (g2 << 1)) << 4) + WG_OP_BYTES;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) WG_STAGE(t_begin, 0);
+  int buf = 0;
+  for (int t0 = t_begin; t0 < t_end; t0 += 64, buf ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of stage `buf` has landed
+    if (t_end - t0 < 64) {                // zero the rows past the token range (both operands)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 4 + kq;
+        if (t0 + r >= t_end) {
+          char* d = wg + buf * WG_STAGE_BYTES + r * 256 + l15 * 16;
+          *reinterpret_cast<uint4*>(d) = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(d + WG_OP_BYTES) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
+    __syncthreads();   // stage `buf` complete; every wave has finished reading stage buf^1
+    if (t0 + 64 < t_end) WG_STAGE(t0 + 64, buf ^ 1);
+    const char* sb = wg + buf * WG_STAGE_BYTES;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = tr16(sb + st * 8192 + offa[i]), hi = tr16(sb + st * 8192 + 1024 + offa[i]);
+        a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 lo = tr16(sb + st * 8192 + offb[j]), hi = tr16(sb + st * 8192 + 1024 + offb[j]);
+        b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef WG_STAGE
+#undef WG_DMA
+  if (PARTIAL) {
+    const size_t blk = (size_t)tile * splits + split;
+    f32x4* dst = reinterpret_cast<f32x4*>(part) + blk * 4096 + wave * 1024 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 64] = acc[i][j];
+    return;
+  }
+  // C layout: col = lane&15 -> B column = k index; row = 4*kq + reg -> A row = n index
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + wk * 64 + j * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int nn = n0 + wn * 64 + i * 16 + kq * 4 + e;
+        if (nn < N && kk < K) atomicAdd(dw + (size_t)nn * lddw + kk, acc[i][j][e]);
+      }
+    }
+}
+
+// dW += sum over splits of the partial tiles of k_wgrad128_bf16<true>.  A block owns 64 float4 of a tile (one fragment: 4
+// consecutive n at one k per lane); its four waves each sum a quarter of the splits (8 independent loads in flight), the
+// quarters are combined through LDS in a fixed order.  64 blocks per tile.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int splits, float* __restrict__ dw, int lddw, int N,
+                                                      int K, int tiles_n) {
+  __shared__ f32x4 red[3][64];
+  const int tile = blockIdx.x >> 6, frag = blockIdx.x & 63, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int wave = frag >> 4, i = (frag >> 2) & 3, j = frag & 3, l15 = lane & 15, kq = lane >> 4;
+  const int per = (splits + 3) >> 2;
+  const int s0 = grp * per, s1 = min(splits, s0 + per);
+  const f32x4* src = reinterpret_cast<const f32x4*>(part) + (size_t)tile * splits * 4096 + frag * 64 + lane;
+  f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int sp = s0;
+  for (; sp + 8 <= s1; sp += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sp + u) * 4096];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; sp < s1; ++sp) sum += src[(size_t)sp * 4096];
+  if (grp) red[grp - 1][lane] = sum;
+  __syncthreads();
+  if (grp) return;
+  sum += red[0][lane];
+  sum += red[1][lane];
+  sum += red[2][lane];
+  const int n0 = (tile % tiles_n) * 128, k0 = (tile / tiles_n) * 128;
+  const int kk = k0 + (wave >> 1) * 64 + j * 16 + l15;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int nn = n0 + (wave & 1) * 64 + i * 16 + kq * 4 + e;
+    if (nn < N && kk < K) dw[(size_t)nn * lddw + kk] += sum[e];
+  }
+}
+
 // naive fp32 variant (gradient checks): thread per output element, block 16 x 16, token range per blockIdx.z
 __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                    float* __restrict__ dw, int lddw, int L, int N, int K, int tokens_per_block) {
@@ -476,16 +670,55 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ dy,
   if (n < N && k < K) atomicAdd(dw + (size_t)n * lddw + k, acc);
 }
 
-int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, hipStream_t s) {
+static int wgrad_target_blocks() {
+  static const int v = getenv("TTV_WGRAD_BLOCKS") ? atoi(getenv("TTV_WGRAD_BLOCKS")) : 384;
+  return v < 1 ? 1 : v;
+}
+static void wgrad_plan(int L, int N, int K, int* splits, int* tpb) {
+  const int nb = ttv_cdiv(N, 128) * ttv_cdiv(K, 128);
+  // token ranges: a multiple of 8 (one per XCD and round), about wgrad_target_blocks() blocks in all - the per-block tile
+  // write-out is the fixed cost, so more blocks than ~2 per CU only add traffic
+  int sp = 8 * ((wgrad_target_blocks() + 4 * nb) / (8 * nb));
+  if (sp < 8) sp = 8;
+  if (sp > ttv_cdiv(L, 64)) sp = ttv_cdiv(L, 64);
+  if (sp < 1) sp = 1;
+  *tpb = ttv_cdiv(ttv_cdiv(L, sp), 64) * 64;
+  *splits = ttv_cdiv(L, *tpb);
+}
+int64_t ttvk_wgrad_ws_bytes(int L, int N, int K) {
+  if (L <= 0 || N <= 0 || K <= 0) return 0;
+  int splits, tpb;
+  wgrad_plan(L, N, K, &splits, &tpb);
+  return (int64_t)ttv_cdiv(N, 128) * ttv_cdiv(K, 128) * splits * 65536;
+}
+
+int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, float* part,
+               int64_t part_bytes, hipStream_t s) {
   if (L == 0 || N == 0 || K == 0) return TTV_OK;
   if (dt == TTV_BF16 && N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0) {
-    const int nb = ttv_cdiv(N, 64) * ttv_cdiv(K, 64);
-    int splits = ttv_cdiv(2048, nb);   // aim at >= 2048 blocks
-    if (splits > ttv_cdiv(L, 64)) splits = ttv_cdiv(L, 64);
-    if (splits < 1) splits = 1;
-    const int tpb = ttv_cdiv(ttv_cdiv(L, splits), 64) * 64;
-    dim3 grid(ttv_cdiv(N, 64), ttv_cdiv(K, 64), ttv_cdiv(L, tpb));
-    hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K, tpb);
+    static const int wg_tile64 = getenv("TTV_WGRAD_TILE64") ? 1 : 0;
+    if (!wg_tile64 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0)) {
+      int splits, tpb;
+      wgrad_plan(L, N, K, &splits, &tpb);
+      const int tn = ttv_cdiv(N, 128), tk = ttv_cdiv(K, 128);
+      dim3 grid(tn * tk * (splits >= 8 ? 8 * ttv_cdiv(splits, 8) : splits));
+      if (part && part_bytes >= (int64_t)tn * tk * splits * 65536 && ((uintptr_t)part % 16 == 0)) {
+        hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
+                           tpb, part, tn, tk, splits);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(tn * tk * 64), dim3(256), 0, s, part, splits, dw, lddw, N, K, tn);
+      } else {
+        hipLaunchKernelGGL(k_wgrad128_bf16<false>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
+                           tpb, nullptr, tn, tk, splits);
+      }
+    } else {
+      const int nb = ttv_cdiv(N, 64) * ttv_cdiv(K, 64);
+      int splits = ttv_cdiv(2048, nb);   // aim at >= 2048 blocks
+      if (splits > ttv_cdiv(L, 64)) splits = ttv_cdiv(L, 64);
+      if (splits < 1) splits = 1;
+      const int tpb = ttv_cdiv(ttv_cdiv(L, splits), 64) * 64;
+      dim3 grid(ttv_cdiv(N, 64), ttv_cdiv(K, 64), ttv_cdiv(L, tpb));
+      hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K, tpb);
+    }
   } else if (dt == TTV_F32) {
     const int tpb = 1024;
     dim3 grid(ttv_cdiv(N, 16), ttv_cdiv(K, 16), ttv_cdiv(L, tpb));

@@ -101,7 +101,10 @@ int ttvk_geglu_bwd(const void* u, int ldu, const void* dh, int lddh, void* du, i
 int ttvk_scale_cast(const float* a, float alpha, float* b, void* c, int dt, long n, hipStream_t s);
 int ttvk_to_f32(const void* a, int dt, float* b, long n, int accumulate, hipStream_t s);
 int ttvk_fsq_bwd(const ttv_fsq_params* fp, const float* z, const void* dcodes, int dt, float* dz, int rows, hipStream_t s);
-int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, hipStream_t s);
+// part / part_bytes: optional scratch for the split partial tiles (ttvk_wgrad_ws_bytes); without it the bf16 path uses fp32 atomics
+int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, float* part,
+               int64_t part_bytes, hipStream_t s);
+int64_t ttvk_wgrad_ws_bytes(int L, int N, int K);
 int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int b_dt, int ldb, const int* b_rows, float* dw, int lddw,
                      int transpose_out, int rows, int d, hipStream_t s);
 int ttvk_expand_small(const void* a, int a_dt, int lda, int C, const void* w, int w_dt, int ldw, int w_cf, void* out, int o_dt, int ldo,

@@ -52,6 +52,8 @@ static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
 struct BwdWs {
   float *dxa, *dxb, *delta, *dkv, *colsum, *small_f32;
   char *g_d, *g_d2, *g_i, *g_2i, *g_nq, *g_pd;
+  float* wg_part;
+  int64_t wg_part_bytes;
   int64_t total;
 };
 static BwdWs carve_bwd(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
@@ -68,6 +70,16 @@ static BwdWs carve_bwd(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
   w.small_f32 = (float*)take(L * dm * 4);          // fp32 [rows, d] scratch for the d <-> token_size projections
   w.g_d = take(L * dm * e); w.g_d2 = take(L * dm * e); w.g_i = take(L * d->inner * e); w.g_2i = take(L * 2 * d->inner * e);
   w.g_nq = take(L * nq * e); w.g_pd = take(P * pd * e);
+  // split partial tiles of the weight-gradient GEMMs (largest of the shapes the tower uses)
+  int64_t wgb = 0;
+  if (d->dtype == TTV_BF16) {
+    const int64_t shapes[6][3] = {{L, dm, d->inner}, {L, 2 * d->inner, dm}, {L, dm, dm}, {L, nq, dm}, {P, dm, pd}, {P, pd, dm}};
+    for (auto& sh : shapes) {
+      const int64_t v = ttvk_wgrad_ws_bytes((int)sh[0], (int)sh[1], (int)sh[2]);
+      wgb = v > wgb ? v : wgb;
+    }
+  }
+  w.wg_part = (float*)take(wgb); w.wg_part_bytes = wgb;
   w.total = off;
   return w;
 }
@@ -150,13 +162,13 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     GemmArgs a = {};
     a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = L; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
     TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, L, dm, I, dt, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, L, dm, I, dt, ws.wg_part, ws.wg_part_bytes, s));
     TTV_TRY(ttvk_geglu_bwd(l.u, 2 * I, ws.g_i, I, ws.g_2i, 2 * I, L, I, dt, s));
     // dxn2 = du W12 ; dW12 += du^T xn2
     GemmArgs c = {};
     c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = L; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, c, s));
-    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, s));
+    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
     // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2)
     TTV_TRY(ttvk_rmsnorm_bwd(l.x1, dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.ffd_norm, dx1, TTV_F32, dm, nullptr, 1, lg.ffd_norm, L, dm, d->eps, s));
     // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
@@ -170,7 +182,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     GemmArgs e = {};
     e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = L; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, e, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.ag, dm, lg.out_proj, dm, L, dm, dm, dt, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.ag, dm, lg.out_proj, dm, L, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
     // da = dag*sigmoid(gate) (into g_d) ; dgate -> dqkvg[:, d:2d]
     char* dqkvg = ws.g_nq;
     const size_t es = esz(dt);
@@ -185,7 +197,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     GemmArgs q = {};
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, q, s));
-    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, s));
+    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
     // dx += rmsnorm_bwd(X[i], pre_ln, dxn1)
     TTV_TRY(ttvk_rmsnorm_bwd(t.X[i], dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.pre_ln, dx, TTV_F32, dm, nullptr, 1, lg.pre_ln, L, dm, d->eps, s));
   }
@@ -259,7 +271,7 @@ int ttv_encoder_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, co
   TTV_TRY(ttvk_rmsnorm_bwd(t.pe, dt, dm, nullptr, ws.dxa, TTV_F32, dm, b->patch_rows, w->ln_pre_p, ws.g_d, dt, dm, nullptr, 0, gr->ln_pre_p, P, dm, d->eps, s));  // dpe
   TTV_TRY(ttvk_sumall(ws.g_d, dt, dm, nullptr, P, dm, nullptr, 1.f, gr->mask_token, s));
   TTV_TRY(ttvk_colsum(ws.g_d, dt, dm, nullptr, P, dm, gr->proj_in_b, s));
-  TTV_TRY(ttvk_wgrad(ws.g_d, dm, t.patches, pd, gr->proj_in_w, pd, P, dm, pd, dt, s));
+  TTV_TRY(ttvk_wgrad(ws.g_d, dm, t.patches, pd, gr->proj_in_w, pd, P, dm, pd, dt, ws.wg_part, ws.wg_part_bytes, s));
   if (dclips) {
     GemmArgs a = {};
     a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = wt->proj_in_t; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.g_pd; a.ldy = pd;
@@ -314,7 +326,7 @@ int ttv_decoder_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, co
     TTV_TRY(ttvk_patch_copy(false, (void* const*)(dclips_out + c0), b->clip_desc, c0, n, d->patch_t, d->patch_h, d->patch_w, d->pix_channels, ws.g_pd, pd, dt, b->max_patches_per_clip, s));
   }
   TTV_TRY(ttvk_colsum(ws.g_pd, dt, pd, nullptr, P, pd, gr->proj_out_b, s));
-  TTV_TRY(ttvk_wgrad(ws.g_pd, pd, t.pn, dm, gr->proj_out_w, dm, P, pd, dm, dt, s));
+  TTV_TRY(ttvk_wgrad(ws.g_pd, pd, t.pn, dm, gr->proj_out_w, dm, P, pd, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
   GemmArgs a = {};
   a.dtype = dt; a.x = ws.g_pd; a.ldx = pd; a.w = wt->proj_out_t; a.ldw = pd; a.M = P; a.N = dm; a.K = pd; a.y = ws.g_d2; a.ldy = dm;   // dpn
   TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
@@ -334,9 +346,13 @@ int ttv_decoder_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, co
   return TTV_OK;
 }
 
-int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype, void* stream) {
+int64_t ttv_linear_wgrad_workspace_bytes(int L, int N, int K) { return ttvk_wgrad_ws_bytes(L, N, K); }
+
+int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
   TTV_CHECK_ARG(L == 0 || (dy && x && dw), "linear_wgrad: null buffer");
-  return ttvk_wgrad(dy, lddy, x, ldx, dw, lddw, L, N, K, dtype, (hipStream_t)stream);
+  TTV_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "linear_wgrad: bad workspace");
+  return ttvk_wgrad(dy, lddy, x, ldx, dw, lddw, L, N, K, dtype, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const float* gain, void* dx, int lddx, float* dgain, int rows,
