@@ -287,6 +287,14 @@ int ttv_fsq_backward(const ttv_fsq_params* p, const float* z, const void* dcodes
 int64_t ttv_linear_wgrad_workspace_bytes(int L, int N, int K);
 int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dtype,
                      void* workspace, int64_t workspace_bytes, void* stream);
+/* Layer-boundary backward in one row-local pass (base/blocks.py:139-168: x1 = attn_post_ln(alpha*x + attn(pre_ln(x))), the
+ * same shape around the feed-forward): A = dx + rmsnorm_bwd(x, gain1, dy) joins a sub-layer's pre-norm gradient with the
+ * residual gradient; B = rmsnorm_bwd(y, gain2, A) takes it through the KEEL post-norm of the sub-layer below (y = that norm's
+ * fp32 input; y == NULL: B = A).  dx (fp32, in/out) = out_scale * B; cast_out (dtype, may be NULL) = B.  dgain1 / dgain2 fp32
+ * [width], accumulated, may be NULL. */
+int ttv_rmsnorm_backward_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
+                               const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                               int width, float eps, int dtype, void* stream);
 /* RMSNorm backward: dx (dtype), dgain fp32 [width] (accumulated; may be NULL). */
 int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const float* gain, void* dx, int lddx, float* dgain, int rows,
                          int width, float eps, int dtype, void* stream);

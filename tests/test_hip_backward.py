@@ -71,6 +71,49 @@ def test_wgrad(dt, shape, workspace):
         assert torch.equal(outs[0], outs[1])
 
 
+def _rms_bwd_ref(x, gain, dy):
+    xr = x.double().requires_grad_(True)
+    gr = gain.double().requires_grad_(True)
+    yy = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * gr
+    yy.backward(dy.double())
+    return xr.grad, gr.grad
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("second", [False, True])
+@pytest.mark.parametrize("rows,d", [(77, 256), (2051, 256), (33, 512), (9, 1024), (130, 320)])
+def test_rmsnorm_backward_chain(dt, second, rows, d):
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2).to(DT[dt])
+    dy = torch.randn(rows, d, generator=g).to(DT[dt])
+    acc = torch.randn(rows, d, generator=g)
+    y = torch.randn(rows, d, generator=g) * 3
+    g1 = 1 + 0.1 * torch.randn(d, generator=g)
+    g2 = 1 + 0.1 * torch.randn(d, generator=g)
+    alpha = 16.0
+    da, dg1_ref = _rms_bwd_ref(x.float(), g1, dy.float())
+    h = acc.double() + da
+    if second:
+        out, dg2_ref = _rms_bwd_ref(y, g2, h)
+    else:
+        out, dg2_ref = h, None
+    dx = acc.to(DEV).clone()
+    cast = torch.empty(rows, d, dtype=DT[dt], device=DEV)
+    dg1 = torch.zeros(d, device=DEV)
+    dg2 = torch.zeros(d, device=DEV)
+    xd, dyd, yd, g1d, g2d = x.to(DEV), dy.to(DEV), y.to(DEV), g1.to(DEV), g2.to(DEV)
+    _lib.check(L().ttv_rmsnorm_backward_chain(xd.data_ptr(), d, dyd.data_ptr(), d, g1d.data_ptr(), dg1.data_ptr(), dx.data_ptr(), d,
+                                              yd.data_ptr() if second else None, d, g2d.data_ptr() if second else None,
+                                              dg2.data_ptr() if second else None, alpha if second else 1.0, cast.data_ptr(), d, rows, d, 1e-5,
+                                              _lib.dtype_code(DT[dt]), S()), "chain")
+    scale = alpha if second else 1.0
+    assert rel(dx, scale * out) < 1e-5
+    assert rel(cast, out) < (4e-3 if dt == "bf16" else 1e-5)
+    assert rel(dg1, dg1_ref) < 1e-5
+    if second:
+        assert rel(dg2, dg2_ref) < 1e-5
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_rmsnorm_backward(dt):
     rows, d = 77, 256

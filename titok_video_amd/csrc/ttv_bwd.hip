@@ -126,6 +126,202 @@ static int launch_rms_bwd(const void* x, int ldx, const int* xr, const void* dy,
   return TTV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ chained norm backward
+// The backward of a layer boundary is row-local end to end:
+//   h   = acc + rmsnorm_bwd(x, gain1, dy)          (pre-norm of a sub-layer: its gradient joins the residual gradient `acc`)
+//   out = rmsnorm_bwd(y, gain2, h)                 (KEEL post-norm of the sub-layer below; skipped when y == NULL: out = h)
+//   dx  = out_scale * out  (fp32, in place of acc) ; cast_out = (T) out      (alpha * dy and the GEMM operand copy)
+// One kernel instead of rmsnorm_bwd(accumulate) + rmsnorm_bwd + scale_cast: the row is read once (x, dy, acc, y) and written
+// once (dx, cast_out); the three launches moved 9.7 KB per row at width 256, this one moves 4.6 KB.
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_tag) {
+  const int i = __builtin_bit_cast(int, v);
+  int r;
+  switch (ctrl_tag) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
+    case 1: r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
+    case 2: r = __builtin_amdgcn_update_dpp(0, i, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
+    default: r = __builtin_amdgcn_update_dpp(0, i, 0x140, 0xF, 0xF, true); break;  // row_mirror
+  }
+  return __builtin_bit_cast(float, r);
+}
+// 64-lane sum: four DPP steps inside the 16-lane rows, two cross-row exchanges
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f(v, 0);
+  v += dpp_f(v, 1);
+  v += dpp_f(v, 2);
+  v += dpp_f(v, 3);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void k_rmsnorm_bwd_chain(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                           const float* __restrict__ gain1, float* __restrict__ dgain1, float* dx, int lddx,
+                                                           const float* __restrict__ y, int ldy, const float* __restrict__ gain2,
+                                                           float* __restrict__ dgain2, float out_scale, T* __restrict__ cast_out, int ldc,
+                                                           int rows, int d, float eps, int rows_per_wave) {
+  __shared__ float red[4][ITERS * 256];
+  constexpr int RB = ITERS == 1 ? 4 : 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool second = y != nullptr;
+  const float inv_d = 1.0f / (float)d;
+  f32x4 g1[ITERS], g2[ITERS], dg1[ITERS], dg2[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    g1[it] = c < d ? *reinterpret_cast<const f32x4*>(gain1 + c) : z;
+    g2[it] = (second && c < d) ? *reinterpret_cast<const f32x4*>(gain2 + c) : z;
+    dg1[it] = z;
+    dg2[it] = z;
+  }
+  const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+  const int r_end = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+  for (int rb = r0; rb < r_end; rb += RB) {
+    f32x4 xv[RB][ITERS], gv[RB][ITERS], hv[RB][ITERS], yv[RB][ITERS];
+    float ss1[RB], ss2[RB], dot[RB], rstd1[RB], rstd2[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int r = rb + q < r_end ? rb + q : r_end - 1;
+      ss1[q] = 0.f;
+      ss2[q] = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        xv[q][it] = z; gv[q][it] = z; hv[q][it] = z; yv[q][it] = z;
+        if (c < d) {
+          xv[q][it] = Vec4<T>::load(x + (size_t)r * ldx + c);
+          gv[q][it] = Vec4<T>::load(dy + (size_t)r * lddy + c);
+          hv[q][it] = *reinterpret_cast<const f32x4*>(dx + (size_t)r * lddx + c);
+          if (second) yv[q][it] = *reinterpret_cast<const f32x4*>(y + (size_t)r * ldy + c);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ss1[q] = fmaf(xv[q][it][e], xv[q][it][e], ss1[q]);
+          ss2[q] = fmaf(yv[q][it][e], yv[q][it][e], ss2[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) ss1[q] = wave_sum_dpp(ss1[q]);
+    if (second) {
+#pragma unroll
+      for (int q = 0; q < RB; ++q) ss2[q] = wave_sum_dpp(ss2[q]);
+    }
+    // stage 1: h = acc + rstd1 * (g1*dy - xhat * mean(g1*dy*xhat)) ; dgain1 += dy * xhat
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const bool live = rb + q < r_end;
+      rstd1[q] = 1.0f / sqrtf(ss1[q] * inv_d + eps);
+      rstd2[q] = 1.0f / sqrtf(ss2[q] * inv_d + eps);
+      dot[q] = 0.f;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = xv[q][it][e] * rstd1[q];
+          if (live) dg1[it][e] = fmaf(gv[q][it][e], xh, dg1[it][e]);
+          gv[q][it][e] *= g1[it][e];
+          dot[q] = fmaf(gv[q][it][e], xh, dot[q]);
+          xv[q][it][e] = xh;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) dot[q] = wave_sum_dpp(dot[q]) * inv_d;
+#pragma unroll
+    for (int q = 0; q < RB; ++q)
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[q][it][e] += rstd1[q] * (gv[q][it][e] - xv[q][it][e] * dot[q]);
+    // stage 2: out = rstd2 * (g2*h - yhat * mean(g2*h*yhat)) ; dgain2 += h * yhat
+    if (second) {
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const bool live = rb + q < r_end;
+        dot[q] = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yh = yv[q][it][e] * rstd2[q];
+            if (live) dg2[it][e] = fmaf(hv[q][it][e], yh, dg2[it][e]);
+            hv[q][it][e] *= g2[it][e];
+            dot[q] = fmaf(hv[q][it][e], yh, dot[q]);
+            yv[q][it][e] = yh;
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < RB; ++q) dot[q] = wave_sum_dpp(dot[q]) * inv_d;
+#pragma unroll
+      for (int q = 0; q < RB; ++q)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[q][it][e] = rstd2[q] * (hv[q][it][e] - yv[q][it][e] * dot[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      if (rb + q >= r_end) continue;
+      const int r = rb + q;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < d) {
+          if (cast_out) Vec4<T>::store(cast_out + (size_t)r * ldc + c, hv[q][it]);
+          *reinterpret_cast<f32x4*>(dx + (size_t)r * lddx + c) = hv[q][it] * out_scale;
+        }
+      }
+    }
+  }
+  // gain gradients: block-level sum through LDS, one atomicAdd per column per block
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dgain = pass ? dgain2 : dgain1;
+    if (pass && !second) break;
+    if (!dgain) continue;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < d) *reinterpret_cast<f32x4*>(&red[wave][c]) = pass ? dg2[it] : dg1[it];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dgain + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
+template <typename T, int ITERS>
+static void launch_rms_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
+                             const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                             int d, float eps, hipStream_t s) {
+  int rpw = ttv_cdiv(rows, 4 * 512);
+  if (rpw < 1) rpw = 1;
+  hipLaunchKernelGGL((k_rmsnorm_bwd_chain<T, ITERS>), dim3(ttv_cdiv(rows, 4 * rpw)), dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy,
+                     gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, (T*)cast_out, ldc, rows, d, eps, rpw);
+}
+
+int ttvk_rmsnorm_bwd_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
+                           const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                           int d, float eps, int dt, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "rmsnorm_bwd_chain: width");
+  TTV_CHECK_ARG(dt == TTV_BF16 || dt == TTV_F32, "rmsnorm_bwd_chain: dtype");
+  TTV_CHECK_ARG(!y || gain2, "rmsnorm_bwd_chain: second norm needs its gain");
+  const int iters = ttv_cdiv(d, 256);
+#define RC(T, I) launch_rms_chain<T, I>(x, ldx, dy, lddy, gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, cast_out, ldc, rows, d, eps, s)
+  if (dt == TTV_BF16) {
+    if (iters == 1) RC(bf16_t, 1); else if (iters == 2) RC(bf16_t, 2); else RC(bf16_t, 4);
+  } else {
+    if (iters == 1) RC(float, 1); else if (iters == 2) RC(float, 2); else RC(float, 4);
+  }
+#undef RC
+  TTV_CHECK_LAUNCH("rmsnorm_bwd_chain");
+  return TTV_OK;
+}
+
 // x dtype, dy dtype, dx dtype codes: TTV_BF16 / TTV_F32
 int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void* dy, int dy_dt, int lddy, const int* dyr,
                      const float* gain, void* dx, int dx_dt, int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps,

@@ -149,13 +149,17 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     const ttv_layer_grads& lg = gr->layers[i];
     Tape::L& l = t.l[i];
     // ---------------- feed-forward sub-layer: X[i+1] = post_ln(alpha*x1 + w3 h)  (layer 0: x1 + w3 h) ----------------
+    // The top layer undoes its feed-forward post-norm here; for the layers below it was chained onto the pre_ln backward of the
+    // layer above (end of the previous iteration).
     float* dx1;
-    if (i > 0) {
-      TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, L, dm, d->eps, s));
-      // tmp = dy2 ; df (T) = dy2 ; dx1 = alpha * dy2 (into dx)
-      TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLd, s));
-    } else {
-      TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, ws.g_d, dt, nLd, s));   // df = (T) dx ; dx1 = dx
+    if (i == d->layers - 1) {
+      if (i > 0) {
+        TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, L, dm, d->eps, s));
+        // tmp = dy2 ; df (T) = dy2 ; dx1 = alpha * dy2 (into dx)
+        TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLd, s));
+      } else {
+        TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, ws.g_d, dt, nLd, s));   // df = (T) dx ; dx1 = dx
+      }
     }
     dx1 = dx;
     // dh = df W3 ; dW3 += df^T h
@@ -169,15 +173,12 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = L; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, c, s));
     TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
-    // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2)
-    TTV_TRY(ttvk_rmsnorm_bwd(l.x1, dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.ffd_norm, dx1, TTV_F32, dm, nullptr, 1, lg.ffd_norm, L, dm, d->eps, s));
+    // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2), then straight through the attention sub-layer's post-norm:
     // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
-    if (i > 0) {
-      TTV_TRY(ttvk_rmsnorm_bwd(l.y1, TTV_F32, dm, nullptr, dx1, TTV_F32, dm, nullptr, lw.attn_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.attn_post_ln, L, dm, d->eps, s));
-      TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLd, s));   // do = (T) dy1 ; dx = alpha * dy1
-    } else {
-      TTV_TRY(ttvk_scale_cast(dx1, 1.f, nullptr, ws.g_d, dt, nLd, s));
-    }
+    // i > 0: dy1 = rmsnorm_bwd(y1, attn_post_ln, dx1) ; do = (T) dy1 ; dx = alpha * dy1      i == 0: do = (T) dx1 ; dx = dx1
+    TTV_TRY(ttvk_rmsnorm_bwd_chain(l.x1, dm, ws.g_d2, dm, lw.ffd_norm, lg.ffd_norm, dx1, dm, i > 0 ? l.y1 : nullptr, dm,
+                                   i > 0 ? lw.attn_post_ln : nullptr, i > 0 ? lg.attn_post_ln : nullptr, i > 0 ? d->alpha : 1.f, ws.g_d, dm, L,
+                                   dm, d->eps, dt, s));
     // dag = do Wo ; dWo += do^T ag
     GemmArgs e = {};
     e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = L; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
@@ -198,8 +199,16 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, q, s));
     TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
-    // dx += rmsnorm_bwd(X[i], pre_ln, dxn1)
-    TTV_TRY(ttvk_rmsnorm_bwd(t.X[i], dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.pre_ln, dx, TTV_F32, dm, nullptr, 1, lg.pre_ln, L, dm, d->eps, s));
+    // dx += rmsnorm_bwd(X[i], pre_ln, dxn1) = dL/dX[i]; chained with the head of the layer below: through its feed-forward
+    // post-norm (layers >= 1) and the bf16 copy df that its w3 products read
+    if (i == 0) {
+      TTV_TRY(ttvk_rmsnorm_bwd(t.X[i], dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.pre_ln, dx, TTV_F32, dm, nullptr, 1, lg.pre_ln, L, dm, d->eps, s));
+    } else {
+      const bool post = i - 1 > 0;
+      TTV_TRY(ttvk_rmsnorm_bwd_chain(t.X[i], dm, ws.g_d2, dm, lw.pre_ln, lg.pre_ln, dx, dm, post ? t.l[i - 1].y2 : nullptr, dm,
+                                     post ? w->layers[i - 1].ffd_post_ln : nullptr, post ? gr->layers[i - 1].ffd_post_ln : nullptr,
+                                     post ? d->alpha : 1.f, ws.g_d, dm, L, dm, d->eps, dt, s));
+    }
   }
   return TTV_OK;
 }
@@ -353,6 +362,14 @@ int ttv_linear_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw
   TTV_CHECK_ARG(L == 0 || (dy && x && dw), "linear_wgrad: null buffer");
   TTV_CHECK_ARG(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "linear_wgrad: bad workspace");
   return ttvk_wgrad(dy, lddy, x, ldx, dw, lddw, L, N, K, dtype, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ttv_rmsnorm_backward_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
+                               const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                               int width, float eps, int dtype, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (x && dy && gain1 && dx), "rmsnorm_backward_chain: null buffer");
+  return ttvk_rmsnorm_bwd_chain(x, ldx, dy, lddy, gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, cast_out, ldc, rows, width, eps,
+                                dtype, (hipStream_t)stream);
 }
 
 int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const float* gain, void* dx, int lddx, float* dgain, int rows,
