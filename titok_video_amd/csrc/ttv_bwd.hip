@@ -1116,52 +1116,28 @@ __device__ __forceinline__ bf16x8 frag_col(const uint4* tile, int row0, int col0
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// S^T and dP^T for a 64-key x 64-query block pair, wave (wa, wb) owns keys wa*32.. x queries wb*32.. :
-//   st[i][j]  = sum_d K[key][d] Q[q][d]      (A = K rows, B = Q rows)  -> lane: 4 consecutive KEYS (rows) for query col l15
-// Returns P^T and dS^T (scaled) in the same layout.
-struct PdS { f32x4 p[2][2], ds[2][2]; };
-__device__ __forceinline__ PdS attn_recompute(const uint4* kt, const uint4* vt, const uint4* qt, const uint4* dot_, int wa, int wb,
-                                              int lane, const float* lse_q, const float* delta_q, int key0, int q0, int S, float scale) {
-  const int l15 = lane & 15, kq = lane >> 4;
-  PdS r;
+// 64 x 64 bf16 tile -> swizzled LDS tile by LDS-DMA (no register round trip, no ds_write): wave w issues the two
+// instructions covering rows 16w .. 16w+15 (8 rows = 1 KB each).  The DMA writes lane l at LDS offset 16 l, so the swizzle is
+// applied on the global side: the lane fetches the chunk that belongs at its LDS position.  Rows past row_last are fetched
+// from row_last (valid memory, finite values); their scores are masked by the callers.
+__device__ __forceinline__ void dma_tile64(uint32_t lds_tile, const bf16_t* base, int ld, int row0, int row_last, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { r.p[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; r.ds[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 ak[2], av[2], bq[2], bd[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ak[i] = frag_row(kt, wa * 32 + i * 16 + l15, ks * 4 + kq);
-      av[i] = frag_row(vt, wa * 32 + i * 16 + l15, ks * 4 + kq);
-      bq[i] = frag_row(qt, wb * 32 + i * 16 + l15, ks * 4 + kq);
-      bd[i] = frag_row(dot_, wb * 32 + i * 16 + l15, ks * 4 + kq);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        r.p[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[i], bq[j], r.p[i][j], 0, 0, 0);    // S^T
-        r.ds[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bd[j], r.ds[i][j], 0, 0, 0);  // dP^T
-      }
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ TSW(r);
+    const int gr = min(row0 + r, row_last);
+    const uint32_t voff = (uint32_t)(gr * ld + c * 8) * 2u;
+    const uint32_t dst = lds_tile + (wave * 2 + i) * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
   }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int qi = wb * 32 + j * 16 + l15;     // query of this lane's column
-    const float l = lse_q[qi], dl = delta_q[qi];
-    const bool qv = q0 + qi < S;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = key0 + wa * 32 + i * 16 + kq * 4 + e;
-        const float p = (qv && key < S) ? __expf(r.p[i][j][e] * scale - l) : 0.f;
-        r.ds[i][j][e] = p * (r.ds[i][j][e] - dl) * scale;
-        r.p[i][j][e] = p;
-      }
-  }
-  return r;
+}
+// 64 floats (one per lane, byte offset voff from base) -> LDS dst .. dst + 255
+__device__ __forceinline__ void dma_f32x64(uint32_t dst, const float* base, uint32_t voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
 // Fragment for a contraction over 32 ROWS of a row-major tile taken in the order of a C-layout accumulator pair
@@ -1184,13 +1160,17 @@ __device__ __forceinline__ bf16x8 pack_pair(f32x4 lo, f32x4 hi) {
 //   dV^T[d][key] += dO^T[d][q] P[q][key],   dK^T[d][key] += Q^T[d][q] dS[q][key],
 // whose A operands are transposed reads of the dO / Q tiles.  Each wave accumulates all 64 d for its 32 keys over its 32
 // queries; the two waves of a key half are summed once at the end.
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
-                                                      const float* __restrict__ lse, const float* __restrict__ delta,
-                                                      const int* __restrict__ cu, const int* __restrict__ blocks, bf16_t* __restrict__ dqkvg,
-                                                      int ldg, int hq, int hkv, float scale) {
-  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], red[2048];
-  __shared__ __attribute__((aligned(16))) float lse_s[64], delta_s[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// The block's K / V rows are the B operands of S and dP in every step: their fragments are loaded from global once and stay
+// in registers.  The streamed Q / dO tiles (and the lse / delta rows) arrive by LDS-DMA into two stages, one step ahead: one
+// barrier per step, nothing of the staging passes through VGPRs.
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         const int* __restrict__ cu, const int* __restrict__ blocks,
+                                                         bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale) {
+  __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];   // Q stages 0/1, dO stages 0/1; the final cross-wave sum reuses it
+  __shared__ __attribute__((aligned(16))) float ls[2][2][64];     // [stage][lse | delta][query]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
   const int seq = blocks[2 * blockIdx.x], key0 = blocks[2 * blockIdx.x + 1];
@@ -1198,41 +1178,49 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int d_model = hq * 64, gqa = hkv * 64, rep = hq / hkv;
   const bf16_t* base = qkvg + (size_t)s0 * ld;
-  stage_tile64(kt, base + 2 * d_model + kvh * 64, ld, key0, S, tid);
-  stage_tile64(vt, base + 2 * d_model + gqa + kvh * 64, ld, key0, S, tid);
+  const bf16_t* dbase = dout + (size_t)s0 * ldd;
+  const uint32_t tiles_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&tiles[0];
+  const uint32_t ls_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&ls[0][0][0];
+  const int nqb = (S + 63) / 64, nsteps = rep * nqb;
+#define DKV_ISSUE(step_, buf_)                                                                              \
+  do {                                                                                                      \
+    const int hr__ = (step_) / nqb, q0__ = ((step_) - hr__ * nqb) * 64, h__ = kvh * rep + hr__;             \
+    dma_tile64(tiles_lds + (buf_) * 8192, base + h__ * 64, ld, q0__, S - 1, wave, lane);                    \
+    dma_tile64(tiles_lds + 16384 + (buf_) * 8192, dbase + h__ * 64, ldd, q0__, S - 1, wave, lane);          \
+    if (wave == 0) {                                                                                        \
+      const uint32_t vo__ = (uint32_t)((s0 + min(q0__ + lane, S - 1)) * hq + h__) * 4u;                     \
+      dma_f32x64(ls_lds + (buf_) * 512, lse, vo__);                                                         \
+      dma_f32x64(ls_lds + (buf_) * 512 + 256, delta, vo__);                                                 \
+    }                                                                                                       \
+  } while (0)
+  DKV_ISSUE(0, 0);
+  bf16x8 bk[2][2], bv[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int key = min(key0 + wb * 32 + j * 16 + l15, S - 1);
+    const bf16_t* kr = base + (size_t)key * ld + 2 * d_model + kvh * 64 + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bk[ks][j] = *reinterpret_cast<const bf16x8*>(kr + ks * 32);
+      bv[ks][j] = *reinterpret_cast<const bf16x8*>(kr + gqa + ks * 32);
+    }
+  }
   f32x4 dk[4][2], dv[4][2];   // [d tile][key tile of this wave]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  // the (q-head, 64-query block) pairs are walked as one sequence; the tiles of step n+1 are loaded to registers while step n
-  // computes
-  const int nqb = (S + 63) / 64, nsteps = rep * nqb;
-  const bf16_t* dbase = dout + (size_t)s0 * ldd;
-  TileRegs rq = load_tile64(base + (kvh * rep) * 64, ld, 0, S, tid), rd = load_tile64(dbase + (kvh * rep) * 64, ldd, 0, S, tid);
-  float rl = 0.f, rdl = 0.f;
-  if (tid < 64) {
-    rl = tid < S ? lse[(size_t)(s0 + tid) * hq + kvh * rep] : 0.f;
-    rdl = tid < S ? delta[(size_t)(s0 + tid) * hq + kvh * rep] : 0.f;
-  }
   for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
     const int hr = step / nqb, q0 = (step - hr * nqb) * 64;
-    __syncthreads();
-    store_tile64(qt, rq, tid);
-    store_tile64(dt_, rd, tid);
-    if (tid < 64) { lse_s[tid] = rl; delta_s[tid] = rdl; }
-    if (step + 1 < nsteps) {
-      const int hr1 = (step + 1) / nqb, q1 = (step + 1 - hr1 * nqb) * 64, h1 = kvh * rep + hr1;
-      rq = load_tile64(base + h1 * 64, ld, q1, S, tid);
-      rd = load_tile64(dbase + h1 * 64, ldd, q1, S, tid);
-      if (tid < 64) {
-        const int q = q1 + tid;
-        rl = q < S ? lse[(size_t)(s0 + q) * hq + h1] : 0.f;
-        rdl = q < S ? delta[(size_t)(s0 + q) * hq + h1] : 0.f;
-      }
-    }
-    __syncthreads();
-    // S[q][key], dP[q][key]: A = Q / dO rows (queries), B = K / V rows (keys)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of stage `buf` has landed
+    __syncthreads();                      // stage complete; every wave is done with the other stage
+    if (step + 1 < nsteps) DKV_ISSUE(step + 1, buf ^ 1);
+    const uint4* qt = tiles + buf * 512;
+    const uint4* dt_ = tiles + 1024 + buf * 512;
+    const float* lse_s = &ls[buf][0][0];
+    const float* delta_s = &ls[buf][1][0];
+    // S[q][key], dP[q][key]: A = Q / dO rows (queries), B = K / V rows (keys, registers)
     f32x4 sp[2][2], dp[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1240,21 +1228,26 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
       for (int j = 0; j < 2; ++j) { sp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 aq[2], ad[2], bk[2], bv[2];
+      bf16x8 aq[2], ad[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         aq[i] = frag_row(qt, wa * 32 + i * 16 + l15, ks * 4 + kq);
         ad[i] = frag_row(dt_, wa * 32 + i * 16 + l15, ks * 4 + kq);
-        bk[i] = frag_row(kt, wb * 32 + i * 16 + l15, ks * 4 + kq);
-        bv[i] = frag_row(vt, wb * 32 + i * 16 + l15, ks * 4 + kq);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          sp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bk[j], sp[i][j], 0, 0, 0);
-          dp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[i], bv[j], dp[i][j], 0, 0, 0);
+          sp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bk[ks][j], sp[i][j], 0, 0, 0);
+          dp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[i], bv[ks][j], dp[i][j], 0, 0, 0);
         }
+    }
+    // the transposed dO / Q fragments of the second products do not depend on the scores: requested before the exponentials
+    bf16x8 ado[4], aqt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ado[i] = frag_colp(dt_, wa * 32, i * 16, lane);   // rows = d (16 i + l15), k = this wave's 32 queries
+      aqt[i] = frag_colp(qt, wa * 32, i * 16, lane);
     }
     // P = exp(S*scale - lse[q]), dS = P (dP - delta[q]) scale ; lane: queries wa*32 + i*16 + 4kq + e (rows), key column l15
 #pragma unroll
@@ -1276,17 +1269,16 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) { bp[j] = pack_pair(sp[0][j], sp[1][j]); bs[j] = pack_pair(dp[0][j], dp[1][j]); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16x8 ado = frag_colp(dt_, wa * 32, i * 16, lane);   // rows = d (16 i + l15), k = this wave's 32 queries
-      const bf16x8 aqt = frag_colp(qt, wa * 32, i * 16, lane);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        dv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado, bp[j], dv[i][j], 0, 0, 0);
-        dk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqt, bs[j], dk[i][j], 0, 0, 0);
+        dv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[i], bp[j], dv[i][j], 0, 0, 0);
+        dk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqt[i], bs[j], dk[i][j], 0, 0, 0);
       }
-    }
   }
+#undef DKV_ISSUE
   // sum the two query halves: wave wa keeps d tiles {2wa, 2wa+1} and receives them from its partner
+  uint4* red = tiles;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1317,13 +1309,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const bf16_t* __restrict__
 // keys wa*32.. (MFMA rows) x queries wb*32.. (columns): a lane holds 4 consecutive KEYS of one query column = the B fragment of
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (contraction over keys; A = transposed read of the K tile).
 // Each wave accumulates all 64 d for its 32 queries over its 32 keys of every block; the two key halves are summed at the end.
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
-                                                     const float* __restrict__ lse, const float* __restrict__ delta,
-                                                     const int* __restrict__ cu, const int* __restrict__ blocks, bf16_t* __restrict__ dqkvg,
-                                                     int ldg, int hq, int hkv, float scale) {
-  __shared__ __attribute__((aligned(16))) uint4 kt[512], vt[512], qt[512], dt_[512], red[1024];
-  __shared__ float lse_s[64], delta_s[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Mirror image of the kernel above: the block's Q / dO fragments (B operands) and its lse / delta live in registers, the K / V
+// tiles stream through two LDS-DMA stages.
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        const int* __restrict__ cu, const int* __restrict__ blocks,
+                                                        bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale) {
+  __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];   // K stages 0/1, V stages 0/1; the final cross-wave sum reuses it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
   const int seq = blocks[2 * blockIdx.x], q0 = blocks[2 * blockIdx.x + 1];
@@ -1331,40 +1325,90 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const bf16_t* __restrict__ 
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int d_model = hq * 64, gqa = hkv * 64, kvh = h / (hq / hkv);
   const bf16_t* base = qkvg + (size_t)s0 * ld;
-  stage_tile64(qt, base + h * 64, ld, q0, S, tid);
-  stage_tile64(dt_, dout + (size_t)s0 * ldd + h * 64, ldd, q0, S, tid);
-  if (tid < 64) {
-    const int q = q0 + tid;
-    lse_s[tid] = q < S ? lse[(size_t)(s0 + q) * hq + h] : 0.f;
-    delta_s[tid] = q < S ? delta[(size_t)(s0 + q) * hq + h] : 0.f;
+  const bf16_t* kbase = base + 2 * d_model + kvh * 64;
+  const uint32_t tiles_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&tiles[0];
+#define DQ_ISSUE(key0_, buf_)                                                                \
+  do {                                                                                       \
+    dma_tile64(tiles_lds + (buf_) * 8192, kbase, ld, (key0_), S - 1, wave, lane);            \
+    dma_tile64(tiles_lds + 16384 + (buf_) * 8192, kbase + gqa, ld, (key0_), S - 1, wave, lane); \
+  } while (0)
+  DQ_ISSUE(0, 0);
+  bf16x8 bq[2][2], bd[2][2];
+  float lq[2], dl[2];
+  bool qv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qi = q0 + wb * 32 + j * 16 + l15;
+    qv[j] = qi < S;
+    const int q = min(qi, S - 1);
+    const bf16_t* qr = base + (size_t)q * ld + h * 64 + kq * 8;
+    const bf16_t* dr = dout + (size_t)(s0 + q) * ldd + h * 64 + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bq[ks][j] = *reinterpret_cast<const bf16x8*>(qr + ks * 32);
+      bd[ks][j] = *reinterpret_cast<const bf16x8*>(dr + ks * 32);
+    }
+    lq[j] = lse[(size_t)(s0 + q) * hq + h];
+    dl[j] = delta[(size_t)(s0 + q) * hq + h];
   }
   f32x4 dq[4][2];   // [d tile][query tile of this wave]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) dq[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  TileRegs rk = load_tile64(base + 2 * d_model + kvh * 64, ld, 0, S, tid), rv = load_tile64(base + 2 * d_model + gqa + kvh * 64, ld, 0, S, tid);
-  for (int key0 = 0; key0 < S; key0 += 64) {
+  int buf = 0;
+  for (int key0 = 0; key0 < S; key0 += 64, buf ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
-    store_tile64(kt, rk, tid);
-    store_tile64(vt, rv, tid);
-    if (key0 + 64 < S) {   // next K/V tiles in flight behind this step's MFMAs
-      rk = load_tile64(base + 2 * d_model + kvh * 64, ld, key0 + 64, S, tid);
-      rv = load_tile64(base + 2 * d_model + gqa + kvh * 64, ld, key0 + 64, S, tid);
+    if (key0 + 64 < S) DQ_ISSUE(key0 + 64, buf ^ 1);
+    const uint4* kt = tiles + buf * 512;
+    const uint4* vt = tiles + 1024 + buf * 512;
+    // S^T[key][q], dP^T[key][q]: A = K / V rows (keys), B = Q / dO rows (queries, registers)
+    f32x4 sp[2][2], dp[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { sp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ak[2], av[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ak[i] = frag_row(kt, wa * 32 + i * 16 + l15, ks * 4 + kq);
+        av[i] = frag_row(vt, wa * 32 + i * 16 + l15, ks * 4 + kq);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          sp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[i], bq[ks][j], sp[i][j], 0, 0, 0);
+          dp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bd[ks][j], dp[i][j], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    const PdS r = attn_recompute(kt, vt, qt, dt_, wa, wb, lane, lse_s, delta_s, key0, q0, S, scale);
+    bf16x8 akt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) akt[i] = frag_colp(kt, wa * 32, i * 16, lane);   // rows = d (16 i + l15), k = this wave's 32 keys
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = key0 + wa * 32 + i * 16 + kq * 4 + e;
+          const float p = (qv[j] && key < S) ? __expf(sp[i][j][e] * scale - lq[j]) : 0.f;
+          dp[i][j][e] = p * (dp[i][j][e] - dl[j]) * scale;
+        }
     bf16x8 bs[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bs[j] = pack_pair(r.ds[0][j], r.ds[1][j]);
+    for (int j = 0; j < 2; ++j) bs[j] = pack_pair(dp[0][j], dp[1][j]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16x8 a = frag_colp(kt, wa * 32, i * 16, lane);   // rows = d (16 i + l15), k = this wave's 32 keys
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) dq[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bs[j], dq[i][j], 0, 0, 0);
-    }
+      for (int j = 0; j < 2; ++j) dq[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(akt[i], bs[j], dq[i][j], 0, 0, 0);
   }
+#undef DQ_ISSUE
   // sum the two key halves: wave wa keeps d tiles {2wa, 2wa+1}
+  uint4* red = tiles;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
