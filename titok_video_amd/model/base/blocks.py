@@ -85,6 +85,15 @@ class _Tower(nn.Module):
         idx = torch.arange(pt * ph * pw * c).reshape(pt, ph, pw, c).permute(3, 0, 1, 2).reshape(-1)
         return idx
 
+    def _patch_perm_on(self, device) -> torch.Tensor:
+        """The same index map resident on `device`.  Cached: a host->device copy of a pageable tensor synchronises with all
+        queued GPU work, which would serialise the backward pass (and every per-step weight repack) with the host."""
+        cache = self.__dict__.setdefault("_perm_cache", {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = self._patch_perm().to(device)
+        return cache[key]
+
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
         params = list(self.parameters())
         key = (dtype, str(device), _versions(params))
@@ -162,7 +171,7 @@ class _Tower(nn.Module):
 
     def _unpack_grads(self, params, views):
         """Packed-layout fp32 gradients -> gradients in the reference parameter layout/dtype, keyed by parameter id."""
-        perm = self._patch_perm().to(views[0].device)
+        perm = self._patch_perm_on(views[0].device)
         out = {}
         for p, g in zip(params, views):
             if g.dtype != p.dtype:
@@ -251,7 +260,7 @@ class _WeightPack:
             keep.extend([w12f, w3c, woc, wq, out])    # stream-ordered: inputs stay alive with the pack
             return out.data_ptr(), rows
 
-        perm = tower._patch_perm().to(device)
+        perm = tower._patch_perm_on(device)
         if tower.kind == _lib.TTV_ENCODER:
             w_in = tower.proj_in.weight.detach().to(device)[:, perm]
             b_out, w_out = tower.proj_out.bias, tower.proj_out.weight
