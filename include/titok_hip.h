@@ -300,10 +300,13 @@ int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const
                          int width, float eps, int dtype, void* stream);
 /* Attention backward (flash-style recompute from the forward's LSE): qkvg as in ttv_attention, o / dout [L,d], lse fp32
  * [L,q_heads] -> dqkvg [L,2d+2g] (q, k, v column ranges written; gate range untouched).  delta: fp32 [L,q_heads] scratch;
- * dkv_scratch: fp32 [L,2g] scratch (fp32 dtype only). blocks64 / row_seq as in ttv_batch. */
+ * dkv_scratch: fp32 [L,2g] scratch (fp32 dtype only). blocks64 / row_seq as in ttv_batch.  rope_cs (fp32 [L,64] cos|sin as in
+ * ttv_batch, may be NULL): when given, dq and dk are returned as gradients w.r.t. the q / k BEFORE the rotary embedding
+ * (rope.py:19-27), i.e. the transposed rotation is applied in fp32 before the store. */
 int ttv_attention_backward(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                            const int32_t* cu_seqlens, const int32_t* blocks64, int n_blocks64, const int32_t* row_seq, void* dqkvg,
-                           int ldg, float* dkv_scratch, int total_rows, int q_heads, int kv_heads, int dtype, void* stream);
+                           int ldg, float* dkv_scratch, int total_rows, int q_heads, int kv_heads, int dtype, const float* rope_cs,
+                           void* stream);
 /* ttv_attention with an extra fp32 [L,q_heads] log-sum-exp output (training forward). */
 int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
                       int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, float* lse, void* stream);

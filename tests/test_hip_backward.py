@@ -136,7 +136,8 @@ def test_rmsnorm_backward(dt):
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("case", [([(4, 16, 16)], [3]), ([(8, 32, 48), (4, 8, 24), (8, 32, 32)], [5, 3, 70])])
-def test_attention_backward(dt, case):
+@pytest.mark.parametrize("rope", [False, True])
+def test_attention_backward(dt, case, rope):
     shapes, counts = case
     plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
     hq, hkv, d, gq = 4, 2, 256, 128
@@ -173,8 +174,18 @@ def test_attention_backward(dt, case):
     rs = plan.table(5, Lr)
     _lib.check(L().ttv_attention_backward(xd.data_ptr(), ld, o.data_ptr(), d, dod.data_ptr(), d, lse.data_ptr(), delta.data_ptr(),
                                           plan.cu_dev.data_ptr(), bt.data_ptr(), plan.n_blocks64, rs.data_ptr(), dq.data_ptr(), ld,
-                                          scratch.data_ptr(), Lr, hq, hkv, code, S()), "attention_backward")
-    gref = f.grad
+                                          scratch.data_ptr(), Lr, hq, hkv, code, plan.rope_cs.data_ptr() if rope else None, S()),
+               "attention_backward")
+    gref = f.grad.clone()
+    if rope:   # dq, dk come back as gradients w.r.t. the UN-rotated q, k: the transposed rotation of the plain ones
+        cs = plan.rope_cs.cpu().double()
+        cos, sin = cs[:, :32].unsqueeze(1), cs[:, 32:].unsqueeze(1)
+
+        def unrotate(gpart):
+            gh = gpart.unflatten(-1, (-1, 32, 2))
+            return torch.stack((gh[..., 0] * cos + gh[..., 1] * sin, gh[..., 1] * cos - gh[..., 0] * sin), -1).flatten(-3)
+        gref[:, :d] = unrotate(gref[:, :d])
+        gref[:, 2 * d:2 * d + gq] = unrotate(gref[:, 2 * d:2 * d + gq])
     tol = 2.5e-2 if dt == "bf16" else 2e-4
     assert rel(dq[:, :d].float(), gref[:, :d]) < tol                     # dq
     assert rel(dq[:, 2 * d:2 * d + gq].float(), gref[:, 2 * d:2 * d + gq]) < tol   # dk

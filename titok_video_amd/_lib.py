@@ -123,7 +123,7 @@ SYMBOLS = {
     "ttv_linear_wgrad": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
     "ttv_rmsnorm_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "ttv_attention_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, vp]),
+                                         C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_attention_lse": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ttv_rope_table_build": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),

@@ -1116,6 +1116,13 @@ __device__ __forceinline__ bf16x8 frag_col(const uint4* tile, int row0, int col0
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// gradient w.r.t. the un-rotated q / k: the transpose of the rotary map (rope.py:19-27) applied to 4 consecutive dims = 2 pairs;
+// cs -> cos of the two pairs, cs + 32 -> sin.  In fp32, before the single rounding of the store.
+__device__ __forceinline__ f32x4 rope_inverse4(f32x4 v, const float* cs) {
+  const float c0 = cs[0], c1 = cs[1], s0 = cs[32], s1 = cs[33];
+  return (f32x4){v[0] * c0 + v[1] * s0, v[1] * c0 - v[0] * s0, v[2] * c1 + v[3] * s1, v[3] * c1 - v[2] * s1};
+}
+
 // 64 x 64 bf16 tile -> swizzled LDS tile by LDS-DMA (no register round trip, no ds_write): wave w issues the two
 // instructions covering rows 16w .. 16w+15 (8 rows = 1 KB each).  The DMA writes lane l at LDS offset 16 l, so the swizzle is
 // applied on the global side: the lane fetches the chunk that belongs at its LDS position.  Rows past row_last are fetched
@@ -1166,7 +1173,7 @@ __device__ __forceinline__ bf16x8 pack_pair(f32x4 lo, f32x4 hi) {
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          const int* __restrict__ cu, const int* __restrict__ blocks,
-                                                         bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale) {
+                                                         bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale, const float* __restrict__ rope_cs) {
   __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];   // Q stages 0/1, dO stages 0/1; the final cross-wave sum reuses it
   __shared__ __attribute__((aligned(16))) float ls[2][2][64];     // [stage][lse | delta][query]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1299,7 +1306,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16_t* __restric
       const int key = key0 + wb * 32 + j * 16 + l15, d0 = ik * 16 + kq * 4;   // lane: 4 consecutive d (rows) of key (col) l15
       if (key < S) {
         bf16_t* row = dqkvg + (size_t)(s0 + key) * ldg + 2 * d_model + kvh * 64 + d0;
-        Vec4<bf16_t>::store(row, dk[ik][j] + pk);
+        f32x4 gk = dk[ik][j] + pk;
+        if (rope_cs) gk = rope_inverse4(gk, rope_cs + (size_t)(s0 + key) * 64 + (d0 >> 1));
+        Vec4<bf16_t>::store(row, gk);
         Vec4<bf16_t>::store(row + gqa, dv[ik][j] + pv);
       }
     }
@@ -1314,7 +1323,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16_t* __restric
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
                                                         const int* __restrict__ cu, const int* __restrict__ blocks,
-                                                        bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale) {
+                                                        bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale, const float* __restrict__ rope_cs) {
   __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];   // K stages 0/1, V stages 0/1; the final cross-wave sum reuses it
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1422,7 +1431,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16_t* __restrict
       const int ik = wa * 2 + i;
       const f32x4 pq = __builtin_bit_cast(f32x4, red[(((wb * 2 + (1 - wa)) * 2 + i) * 2 + j) * 64 + lane]);
       const int q = q0 + wb * 32 + j * 16 + l15, d0 = ik * 16 + kq * 4;
-      if (q < S) Vec4<bf16_t>::store(dqkvg + (size_t)(s0 + q) * ldg + h * 64 + d0, dq[ik][j] + pq);
+      if (q < S) {
+        f32x4 gq = dq[ik][j] + pq;
+        if (rope_cs) gq = rope_inverse4(gq, rope_cs + (size_t)(s0 + q) * 64 + (d0 >> 1));
+        Vec4<bf16_t>::store(dqkvg + (size_t)(s0 + q) * ldg + h * 64 + d0, gq);
+      }
     }
 }
 
@@ -1430,7 +1443,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16_t* __restrict
 // (fp32 path); dkv_scratch: fp32 [L, 2g] zeroed by this function (fp32 path only).
 int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                        const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
-                       int total_rows, int hq, int hkv, int dt, hipStream_t s) {
+                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s) {
   if (total_rows == 0) return TTV_OK;
   const float scale = 0.125f;
   const int d_model = hq * 64, gqa = hkv * 64;
@@ -1438,9 +1451,9 @@ int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const v
   else hipLaunchKernelGGL((k_attn_delta<float>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const float*)dout, ldd, (const float*)o, ldo, delta, total_rows, hq);
   TTV_CHECK_LAUNCH("attn_delta");
   if (dt == TTV_BF16) {
-    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(n_blocks64, hkv), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale);
+    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(n_blocks64, hkv), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs);
     TTV_CHECK_LAUNCH("attn_bwd_dkv");
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(n_blocks64, hq), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale);
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(n_blocks64, hq), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs);
     TTV_CHECK_LAUNCH("attn_bwd_dq");
   } else {
     TTV_CHECK_ARG(dkv_scratch && row_seq, "attention_bwd: fp32 path needs scratch and row map");
@@ -1450,6 +1463,11 @@ int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const v
     // copy dk|dv scratch [L, 2g] into the k, v columns of dqkvg
     (void)hipMemcpy2DAsync((float*)dqkvg + 2 * d_model, (size_t)ldg * sizeof(float), dkv_scratch, (size_t)2 * gqa * sizeof(float),
                            (size_t)2 * gqa * sizeof(float), total_rows, hipMemcpyDeviceToDevice, s);
+    if (rope_cs) {   // the bf16 kernels rotate in their store; the checking path uses the stand-alone kernel
+      int rc = ttvk_rope_apply_dir(dqkvg, dt, ldg, total_rows, hq, rope_cs, 1, s);
+      if (rc == TTV_OK) rc = ttvk_rope_apply_dir((float*)dqkvg + 2 * d_model, dt, ldg, total_rows, hkv, rope_cs, 1, s);
+      if (rc != TTV_OK) return rc;
+    }
   }
   return TTV_OK;
 }

@@ -190,10 +190,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     TTV_TRY(ttvk_gate_bwd(ws.g_d2, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt, s));
     // attention backward -> dq, dk, dv columns of dqkvg
     TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, ws.g_d, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
-                               ws.dkv, L, d->q_heads, d->kv_heads, dt, s));
-    // inverse rotation of dq and dk
-    TTV_TRY(ttvk_rope_apply_dir(dqkvg, dt, nq, L, d->q_heads, b->rope_cs, 1, s));
-    TTV_TRY(ttvk_rope_apply_dir(dqkvg + (size_t)2 * dm * es, dt, nq, L, d->kv_heads, b->rope_cs, 1, s));
+                               ws.dkv, L, d->q_heads, d->kv_heads, dt, b->rope_cs, s));   // dq, dk come back un-rotated
     // dxn1 = dqkvg Wqkv ; dWqkv += dqkvg^T xn1
     GemmArgs q = {};
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
@@ -380,10 +377,11 @@ int ttv_rmsnorm_backward(const void* x, int ldx, const void* dy, int lddy, const
 
 int ttv_attention_backward(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                            const int32_t* cu_seqlens, const int32_t* blocks64, int n_blocks64, const int32_t* row_seq, void* dqkvg,
-                           int ldg, float* dkv_scratch, int total_rows, int q_heads, int kv_heads, int dtype, void* stream) {
+                           int ldg, float* dkv_scratch, int total_rows, int q_heads, int kv_heads, int dtype, const float* rope_cs,
+                           void* stream) {
   TTV_CHECK_ARG(total_rows == 0 || (qkvg && o && dout && lse && delta && cu_seqlens && blocks64 && dqkvg), "attention_backward: null buffer");
   return ttvk_attention_bwd(qkvg, ld, o, ldo, dout, ldd, lse, delta, cu_seqlens, blocks64, n_blocks64, row_seq, dqkvg, ldg, dkv_scratch,
-                            total_rows, q_heads, kv_heads, dtype, (hipStream_t)stream);
+                            total_rows, q_heads, kv_heads, dtype, rope_cs, (hipStream_t)stream);
 }
 
 int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
