@@ -1,0 +1,176 @@
+"""GAN loss module on the HIP path: `ReconstructionLoss` mirror (L1 + relativistic GAN terms,
+finite-difference R1/R2 penalty, centering) with the discriminator = TiTokEncoder(out_channels=1) on the HIP kernels.  `-m gpu`.
+
+  * fp32: generator / discriminator loss dictionaries against the REFERENCE's own module (tests/golden/loss_kat.npz) and
+    gradients (d generator / d recon through the frozen discriminator; discriminator parameter gradients) against torch
+    autograd through the oracle, 2e-3 relative.
+  * bf16: loss values within 2e-2 of the reference's bf16 run, gradients cosine >= 0.95 with the reference's bf16 gradients.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as LO
+from titok_video_amd.model.losses import ReconstructionLoss
+from titok_video_amd.synthetic import seeded_tower_state, synthetic_clips
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def loss_config(d, disc_weight=None):
+    return SimpleNamespace(
+        tokenizer=SimpleNamespace(losses=SimpleNamespace(disc_weight=float(d["disc_weight"]) if disc_weight is None else disc_weight,
+                                                         perceptual_weight=0.0, gram_weight=0.0, perceptual_samples_per_step=24,
+                                                         perceptual_sampling_size=128)),
+        discriminator=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], model_size="tiny"),
+                                      losses=SimpleNamespace(gp_weight=float(d["gp_weight"]), gp_noise=float(d["gp_noise"]),
+                                                             centering_weight=float(d["centering_weight"]))),
+        training=SimpleNamespace(main=SimpleNamespace(torch_compile=False, max_steps=1000)))
+
+
+def fixture(dtype):
+    d = np.load(os.path.join(G, "loss_kat.npz"))
+    shapes = [tuple(int(v) for v in s) for s in d["shapes"]]
+    target = synthetic_clips(shapes, seed=int(d["clip_seed"]))
+    recon = [torch.from_numpy(d[f"recon{i}"]) for i in range(len(shapes))]
+    noise = [torch.from_numpy(d[f"noise{i}"]) for i in range(len(shapes))]
+    sd = seeded_tower_state("encoder", "tiny", (4, 8, 8), 3, 1, seed=int(d["disc_seed"]))
+    mod = ReconstructionLoss(loss_config(d))
+    mod.disc_model.load_state_dict(sd, strict=True)
+    mod = mod.to(DEV, dtype)
+    to = lambda xs: [x.to(DEV, dtype) for x in xs]
+    return d, mod, sd, target, recon, noise, to
+
+
+def rel(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cos(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+
+def test_state_dict_keys_and_perceptual_guard():
+    d = np.load(os.path.join(G, "loss_kat.npz"))
+    mod = ReconstructionLoss(loss_config(d))
+    keys = list(mod.state_dict().keys())
+    assert keys and all(k.startswith("disc_model.") for k in keys)         # trainer prefix: loss_module.disc_model.* 
+    assert set(k[len("disc_model."):] for k in keys) == set(seeded_tower_state("encoder", "tiny", (4, 8, 8), 3, 1, seed=1).keys())
+    cfg = loss_config(d)
+    cfg.tokenizer.losses.perceptual_weight = 1.0
+    with pytest.raises(NotImplementedError):
+        ReconstructionLoss(cfg)
+    assert not hasattr(ReconstructionLoss(loss_config(d, disc_weight=0.0)), "disc_model")   # loss_module.py:41
+
+
+def test_loss_values_fp32_match_reference_module():
+    d, mod, sd, target, recon, noise, to = fixture(torch.float32)
+    with torch.no_grad():
+        np.testing.assert_allclose(mod.disc_wrapper(to(target)).cpu().numpy(), d["logits_real"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(mod.disc_wrapper(to(recon)).cpu().numpy(), d["logits_fake"], rtol=0, atol=1e-4)
+    tot, gd = mod(to(target), to(recon))
+    assert abs(float(tot) - float(d["gen_total"])) < 1e-4
+    for k in ("recon_loss", "g_loss", "total_loss"):
+        assert abs(float(gd["gen/" + k]) - float(d["gen_" + k])) < 1e-4, k
+    tot, dd = mod(to(target), to(recon), disc_forward=True, gp_noise_tensors=to(noise))
+    assert abs(float(tot) - float(d["disc_total"])) < 3e-3      # R1/R2: squared logit differences scaled by gp_weight / gp_noise^2 = 10
+    for k in ("d_loss", "logits_relative", "r1_penalty", "r2_penalty", "centering_loss", "total_loss"):
+        assert abs(float(dd["disc/" + k]) - float(d["disc_" + k])) < 3e-3, k
+
+
+def test_generator_step_gradients_fp32():
+    """d loss / d recon flows through the FROZEN discriminator (loss_module.py:144-151); its parameters get no gradient."""
+    d, mod, sd, target, recon, noise, to = fixture(torch.float32)
+    rec = [r.requires_grad_(True) for r in to(recon)]
+    tot, _ = mod(to(target), rec)
+    tot.backward()
+    assert all(p.grad is None and not p.requires_grad for p in mod.disc_model.parameters())
+    ref = [r.clone().requires_grad_(True) for r in recon]
+    rt, _ = LO.generator_loss(target, ref, sd, float(d["disc_weight"]))
+    rt.backward()
+    assert abs(float(tot) - float(rt)) < 1e-4
+    for a, b in zip(rec, ref):
+        assert rel(a.grad, b.grad) < 2e-3
+
+
+def test_discriminator_step_gradients_fp32():
+    d, mod, sd, target, recon, noise, to = fixture(torch.float32)
+    tot, _ = mod(to(target), to(recon), disc_forward=True, gp_noise_tensors=to(noise))
+    tot.backward()
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rt, _ = LO.discriminator_loss(target, recon, sdg, float(d["gp_weight"]), float(d["gp_noise"]), float(d["centering_weight"]), noise)
+    rt.backward()
+    assert abs(float(tot) - float(rt)) < 3e-3
+    num = den = 0.0
+    for n, p in mod.disc_model.named_parameters():
+        assert p.requires_grad and p.grad is not None, n
+        g, r = p.grad.double().cpu(), sdg[n].grad.double()
+        num += float((g - r).pow(2).sum())
+        den += float(r.pow(2).sum())
+        if r.numel() >= 4096:
+            assert rel(g, r) < 2e-2, (n, rel(g, r))          # the penalty terms amplify fp32 rounding of nearly equal logits by 10
+    assert (num / den) ** 0.5 < 5e-3
+
+
+def test_bf16_losses_and_gradients_follow_the_reference_bf16_run():
+    d, mod, sd, target, recon, noise, to = fixture(torch.bfloat16)
+    rec = [r.requires_grad_(True) for r in to(recon)]
+    tot, _ = mod(to(target), rec)
+    tot.backward()
+    assert abs(float(tot) - float(d["gen_total_bf16"])) < 2e-2
+    assert abs(float(tot) - float(d["gen_total"])) < 2e-2
+    for i, r in enumerate(rec):
+        assert cos(r.grad.float(), torch.from_numpy(d[f"gen_drecon{i}_bf16"])) > 0.95
+    tot, _ = mod(to(target), to(recon), disc_forward=True, gp_noise_tensors=to(noise))
+    tot.backward()
+    # bf16 logits carry ~4e-3 absolute noise; the R1/R2 terms square logit differences of ~0.1 and scale by 10
+    assert abs(float(tot) - float(d["disc_total"])) < 0.25
+    assert abs(float(tot) - float(d["disc_total_bf16"])) < 0.25
+    grads = dict(mod.disc_model.named_parameters())
+    for n in ("model_layers.attn_layer.0.to_qkv.weight", "model_layers.ffd_layer.3.w3.weight", "proj_out.weight"):
+        assert cos(grads[n].grad.float(), torch.from_numpy(d["disc_grad_bf16::" + n])) > 0.85, n
+    names = [str(x) for x in d["disc_grad_names"]]
+    ref_norm = float(np.sqrt((d["disc_grad_norms_bf16"] ** 2).sum()))
+    got_norm = float(torch.sqrt(sum(grads[n].grad.float().pow(2).sum() for n in names)))
+    assert 0.7 < got_norm / ref_norm < 1.4
+
+
+def test_gan_training_step_runs_and_updates_both_models():
+    """Reference train.py:64-107 on the HIP path: generator step (through the frozen discriminator) then discriminator step."""
+    from titok_video_amd.model.titok import TiTok
+    from titok_video_amd.synthetic import seeded_titok_state
+    from titok_video_amd.train import gan_training_step, make_discriminator_optimizer, make_optimizer
+    d = np.load(os.path.join(G, "loss_kat.npz"))
+    cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5],
+                                                                          encoder_size="tiny", decoder_size="tiny")))
+    model = TiTok(cfg)
+    model.load_state_dict(seeded_titok_state(0))
+    model = model.to(DEV, torch.bfloat16).train()
+    lm = ReconstructionLoss(loss_config(d))
+    lm.disc_model.load_state_dict(seeded_tower_state("encoder", "tiny", (4, 8, 8), 3, 1, seed=77))
+    lm = lm.to(DEV, torch.bfloat16).train()
+    shapes, counts = [(4, 16, 16), (8, 32, 48), (4, 8, 24)], [2, 5, 3]
+    clips = synthetic_clips(shapes, seed=9, dtype=torch.bfloat16, device=DEV)
+    opt_g, opt_d = make_optimizer(model), make_discriminator_optimizer(lm)
+    g0 = [p.detach().clone() for p in model.parameters()]
+    d0 = [p.detach().clone() for p in lm.disc_model.parameters()]
+    first = None
+    for _ in range(3):
+        loss_dict, idx = gan_training_step(model, lm, clips, counts, opt_g, opt_d)
+        first = first or loss_dict
+    assert idx.dtype == torch.int32 and idx.numel() == sum(counts)
+    for k in ("gen/recon_loss", "gen/g_loss", "gen/total_loss", "disc/d_loss", "disc/r1_penalty", "disc/r2_penalty",
+              "disc/centering_loss", "disc/total_loss"):
+        assert k in loss_dict and torch.isfinite(loss_dict[k]).all(), k
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(g0, model.parameters()))
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(d0, lm.disc_model.parameters()))
+    assert all(p.requires_grad for p in lm.disc_model.parameters())            # re-enabled by the discriminator branch
+    # generator total = L1 + disc_weight * g_loss (both reported as means)
+    assert abs(float(first["gen/total_loss"]) - (float(first["gen/recon_loss"]) + float(d["disc_weight"]) * float(first["gen/g_loss"]))) < 2e-2

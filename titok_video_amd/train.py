@@ -4,8 +4,8 @@ model/losses/loss_module.py:118: L1 between target and reconstruction, mean over
     forward (tape) -> L1 loss -> backward (HIP kernels) -> [DP: count-weighted gradient all-reduce over RCCL]
     -> clip_grad_norm(max_grad_norm) -> optimizer.step()
 
-LPIPS and the GAN discriminator are outside this path's scope (they need network-fetched weights, SURVEY.md section 2);
-the discriminator's tower itself is `TiTokEncoder(out_channels=1)` and differentiates through its inputs on this path.
+`gan_training_step` adds the reference's discriminator step (train.py:86-107) on top of `model/losses/loss_module.py`'s
+mirror; LPIPS is outside this path's scope (network-fetched weights).
 """
 from __future__ import annotations
 
@@ -79,3 +79,43 @@ def training_step(model, clips: List[torch.Tensor], token_counts, optimizer, max
     gnorm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     optimizer.step()
     return loss.detach(), gnorm, out["indices"]
+
+
+def make_discriminator_optimizer(loss_module: torch.nn.Module, lr: float = 1e-4, disc_lr_ratio: float = 0.15, beta1: float = 0.5,
+                                 beta2: float = 0.96, weight_decay: float = 1e-4):
+    """AdamW over `loss_module.disc_model` at lr * disc_lr_ratio (reference train.py:195-201, configs/tiny.yaml:46)."""
+    params = list(loss_module.disc_model.parameters())
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return torch.optim.AdamW(params, lr=lr * disc_lr_ratio, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused)
+
+
+def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_counts, opt_g, opt_d=None, max_grad_norm: float = 1.0,
+                      group=None):
+    """One generator step followed by one discriminator step on this rank's clips (reference train.py:64-107).
+
+    generator:      recon = model(clips); loss = loss_module(target=clips, recon=recon)  [L1 + disc_weight * relativistic GAN term
+                    through the frozen discriminator]; backward; clip; opt_g.step()
+    discriminator:  loss_module(target=clips, recon=recon, disc_forward=True)  [both detached inside: relativistic loss + R1/R2
+                    finite-difference penalty + centering]; backward; clip; opt_d.step()      (skipped when disc_weight == 0)
+    Under torch.distributed both gradient sets are reduced as sum(count * grad) / sum(count), as in `training_step`.
+    Returns the merged {'gen/..', 'disc/..'} dictionary of detached scalars and the token indices."""
+    opt_g.zero_grad(set_to_none=True)
+    recon, out = model(clips, token_counts)
+    loss, loss_dict = loss_module(target=clips, recon=recon)
+    loss.backward()
+    g_params = [p for p in model.parameters() if p.grad is not None]
+    dp.allreduce_mean_by_count([p.grad for p in g_params], len(clips), group=group)
+    if max_grad_norm:
+        torch.nn.utils.clip_grad_norm_(g_params, max_grad_norm)
+    opt_g.step()
+    if opt_d is not None and getattr(loss_module, "disc_weight", 0.0) > 0.0:
+        opt_d.zero_grad(set_to_none=True)
+        d_loss, d_dict = loss_module(target=clips, recon=recon, disc_forward=True)
+        loss_dict.update(d_dict)
+        d_loss.backward()
+        d_params = [p for p in loss_module.disc_model.parameters() if p.grad is not None]
+        dp.allreduce_mean_by_count([p.grad for p in d_params], len(clips), group=group)
+        if max_grad_norm:
+            torch.nn.utils.clip_grad_norm_(d_params, max_grad_norm)
+        opt_d.step()
+    return loss_dict, out["indices"]
