@@ -263,7 +263,10 @@ int64_t ttv_tower_bwd_workspace_bytes(const ttv_tower_dims* dims, const ttv_batc
 int ttv_encoder_forward_train(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_batch* batch, const void* const* clips,
                               float* z, void* tape, int64_t tape_bytes, void* stream);
 /* Backward of the above: dz fp32 -> parameter gradients (accumulated) and, if dclips != NULL, gradients w.r.t. the input
- * clips (HOST array of device ptrs, compute dtype; needed by the discriminator path, loss_module.py:149-152). */
+ * clips (HOST array of device ptrs, compute dtype; needed by the discriminator path, loss_module.py:149-152).
+ * grads == NULL (then dclips must be given): all parameters frozen - the generator step through the discriminator,
+ * loss_module.py:144-151 - only the input gradient is computed, the weight-gradient GEMMs and gain / bias reductions are
+ * skipped. */
 int ttv_encoder_backward(const ttv_tower_dims* dims, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* batch,
                          const float* dz, void* tape, const ttv_tower_grads* grads, void* const* dclips, void* workspace,
                          int64_t workspace_bytes, void* stream);

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ a, int lda
 }
 
 int ttvk_colsum(const void* a, int dt, int lda, const int* rows_map, int rows, int n, float* out, hipStream_t s) {
-  if (rows == 0 || n == 0) return TTV_OK;
+  if (rows == 0 || n == 0 || !out) return TTV_OK;   // out == NULL: this parameter's gradient is not wanted
   const int rpb = 128;
   dim3 grid(ttv_cdiv(rows, rpb), ttv_cdiv(n, 256));
   if (dt == TTV_BF16) hipLaunchKernelGGL((k_colsum<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)a, lda, rows_map, rows, n, out, rpb);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_sumall(const T* __restrict__ a, int lda
 
 int ttvk_sumall(const void* a, int dt, int lda, const int* rows_map, int rows, int n, const float* colw, float scale, float* out,
                 hipStream_t s) {
-  if (rows == 0 || n == 0) return TTV_OK;
+  if (rows == 0 || n == 0 || !out) return TTV_OK;
   long total = (long)rows * n;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
@@ -890,7 +890,7 @@ int64_t ttvk_wgrad_ws_bytes(int L, int N, int K) {
 
 int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, float* part,
                int64_t part_bytes, hipStream_t s) {
-  if (L == 0 || N == 0 || K == 0) return TTV_OK;
+  if (L == 0 || N == 0 || K == 0 || !dw) return TTV_OK;   // dw == NULL: frozen weight
   if (dt == TTV_BF16 && N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0) {
     static const int wg_tile64 = getenv("TTV_WGRAD_TILE64") ? 1 : 0;
     if (!wg_tile64 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0)) {
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void k_outer_small(const TA* __restrict__ a, i
 
 int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int b_dt, int ldb, const int* b_rows, float* dw, int lddw,
                      int transpose_out, int rows, int d, hipStream_t s) {
-  if (rows == 0) return TTV_OK;
+  if (rows == 0 || !dw) return TTV_OK;
   TTV_CHECK_ARG(C <= TTV_MAX_FSQ, "outer_small: C");
   const int rpb = 64;
   dim3 grid(ttv_cdiv(rows, rpb));

@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void k_const_rows_bwd(const float* __restrict_
 
 int ttvk_const_rows_bwd(const float* colsum, const float* mask_token, const float* gain, int dt, float eps, float* dgain, float* dmask,
                         int d, hipStream_t s) {
+  if (!dgain && !dmask) return TTV_OK;
   if (dt == TTV_BF16) hipLaunchKernelGGL((k_const_rows_bwd<bf16_t>), dim3(1), dim3(256), 0, s, colsum, mask_token, gain, eps, dgain, dmask, d);
   else hipLaunchKernelGGL((k_const_rows_bwd<float>), dim3(1), dim3(256), 0, s, colsum, mask_token, gain, eps, dgain, dmask, d);
   TTV_CHECK_LAUNCH("const_rows_bwd");

@@ -253,7 +253,15 @@ int ttv_encoder_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* 
 int ttv_encoder_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* b, const float* dz,
                          void* tape, const ttv_tower_grads* gr, void* const* dclips, void* workspace, int64_t workspace_bytes, void* stream) {
   TTV_TRY(check(d, b));
-  TTV_CHECK_ARG(d->kind == TTV_ENCODER && w && wt && wt->layers && gr && gr->layers && dz && tape && workspace, "encoder_backward: bad argument");
+  TTV_CHECK_ARG(d->kind == TTV_ENCODER && w && wt && wt->layers && (!gr || gr->layers) && dz && tape && workspace, "encoder_backward: bad argument");
+  // grads == NULL: every parameter is frozen (generator step through the discriminator, loss_module.py:144-151) - only the
+  // input-clip gradient is produced; all weight-gradient GEMMs, gain / bias reductions are skipped
+  static const ttv_layer_grads no_layer_grads[64] = {};
+  static const ttv_tower_grads no_grads = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, no_layer_grads};
+  if (!gr) {
+    TTV_CHECK_ARG(dclips, "encoder_backward: nothing to compute (no parameter and no input gradients requested)");
+    gr = &no_grads;
+  }
   hipStream_t s = (hipStream_t)stream;
   Tape t = carve_tape(d, b, (char*)tape);
   BwdWs ws = carve_bwd(d, b, (char*)workspace);

@@ -457,16 +457,19 @@ class _EncoderTrainFn(torch.autograd.Function):
     def backward(ctx, dz):
         tower, device = ctx.tower, dz.device
         lib = _lib.lib()
-        flat, views, params, gstruct, _lay = tower._grad_buffers(device)
         ws = torch.empty(int(lib.ttv_tower_bwd_workspace_bytes(C.byref(ctx.dims), C.byref(ctx.batch))), dtype=torch.uint8, device=device)
         dclips = None
         if any(ctx.clip_grad):
             dclips = [torch.empty_like(c) for c in ctx.clips]
+        # every parameter frozen (the generator step through the discriminator, loss_module.py:144-151): inputs-only backward
+        frozen = dclips is not None and not any(p.requires_grad for p in ctx.params)
+        if not frozen:
+            flat, views, params, gstruct, _lay = tower._grad_buffers(device)
         rc = lib.ttv_encoder_backward(C.byref(ctx.dims), C.byref(ctx.pack.struct), C.byref(ctx.pack.transposed()), C.byref(ctx.batch),
-                                      dz.contiguous().float().data_ptr(), ctx.tape.data_ptr(), C.byref(gstruct),
+                                      dz.contiguous().float().data_ptr(), ctx.tape.data_ptr(), None if frozen else C.byref(gstruct),
                                       _lib.ptr_array(dclips) if dclips else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_encoder_backward")
-        by_id = tower._unpack_grads(params, tower._convert_views(flat, views, params))
+        by_id = {} if frozen else tower._unpack_grads(params, tower._convert_views(flat, views, params))
         clip_grads = [dclips[i] if (dclips and ctx.clip_grad[i]) else None for i in range(ctx.n_clips)]
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None

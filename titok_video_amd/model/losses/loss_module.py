@@ -84,18 +84,24 @@ class ReconstructionLoss(nn.Module):
         recon = [i.detach().requires_grad_(True).contiguous() for i in recon]
         for param in self.disc_model.parameters():                     # loss_module.py:172-174
             param.requires_grad = True
-        logits_real = self.disc_wrapper(target)
-        logits_fake = self.disc_wrapper(recon)
+        # The reference makes 2 (+2 with the penalty) discriminator calls; clips are independent inside the tower (block-diagonal
+        # attention, per-row norms), so they are issued here as ONE packed call and the logits split afterwards: same values,
+        # one tape / one backward / one set of weight-gradient launches instead of four.
+        b = len(target)
+        batch = list(target) + list(recon)
+        if self.gp_weight > 0.0:                                       # finite-difference R1 / R2 (loss_module.py:187-198)
+            if noise is None:
+                noise = [torch.randn_like(x) * self.gp_noise for x in target]
+            batch += [x + y for x, y in zip(target, noise)] + [x + y for x, y in zip(recon, noise)]
+        logits = self.disc_wrapper(batch)
+        logits_real, logits_fake = logits[:b], logits[b:2 * b]
         logits_relative = logits_real - logits_fake
         d_loss = F.softplus(-logits_relative)
         loss_dict["d_loss"] = d_loss
         loss_dict["logits_relative"] = logits_relative
         gradient_penalty = 0.0
-        if self.gp_weight > 0.0:                                       # finite-difference R1 / R2 (loss_module.py:187-198)
-            if noise is None:
-                noise = [torch.randn_like(x) * self.gp_noise for x in target]
-            logits_real_noised = self.disc_wrapper([x + y for x, y in zip(target, noise)])
-            logits_fake_noised = self.disc_wrapper([x + y for x, y in zip(recon, noise)])
+        if self.gp_weight > 0.0:
+            logits_real_noised, logits_fake_noised = logits[2 * b:3 * b], logits[3 * b:]
             r1_penalty = (logits_real - logits_real_noised) ** 2
             r2_penalty = (logits_fake - logits_fake_noised) ** 2
             loss_dict["r1_penalty"] = r1_penalty
