@@ -327,7 +327,7 @@ def test_l1_loss_matches_autograd(dt):
     """ttv_l1_loss (value + gradient, one launch) vs torch autograd over the per-clip definition (loss_module.py:118)."""
     from titok_video_amd.train import l1_reconstruction_loss
     g = torch.Generator().manual_seed(3)
-    shapes = [(3, 4, 16, 16), (3, 8, 32, 48), (3, 4, 8, 24)]
+    shapes = [(3, 4, 16, 16), (3, 8, 32, 48), (3, 4, 8, 24), (3, 5, 7, 3)]    # the last one: 315 elements, vector body + scalar tail
     recon = [torch.randn(sh, generator=g).to(dt) for sh in shapes]
     target = [torch.randn(sh, generator=g).to(dt) for sh in shapes]
     target[0][0, 0, 0, :4] = recon[0][0, 0, 0, :4]                            # exact ties -> zero gradient
