@@ -337,7 +337,8 @@ int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, cons
 /* Start recording launches of `kernel_class` (up to max_records; events are created here, outside any launch path).
  * This is the only process-global state in the library and it is off by default. */
 int ttv_prof_begin(int kernel_class, int max_records);
-/* Diagnostics for kernel ablation timing (never set in product use): bit0 = GEMM epilogues skip their stores. */
+/* Diagnostics for kernel ablation timing / tests (never set in product use): bit0 = GEMM epilogues skip their stores;
+ * bit7 (128) / bit8 (256) = force the 160- / 128-token tile of the general-K GEMM instead of the grid-balance choice. */
 int ttv_debug_set(int flags);
 /* Diagnostics: device buffer (>= 256 int64) that instrumented kernels fill with s_memtime stamps of block 0; NULL = off. */
 int ttv_debug_stamps(void* device_buffer);

@@ -150,6 +150,24 @@ def _lin_inputs(M, N, K, dt, seed):
     return x, w, g
 
 
+@pytest.mark.parametrize("tile", [128, 160])
+@pytest.mark.parametrize("shape", [(300, 256, 768), (161, 768, 704), (1, 256, 704), (513, 256, 1376), (4000, 256, 1408)])
+def test_linear_general_k_tile_heights(shape, tile):
+    """General-K bf16 GEMM with the 128- and the 160-token tile forced (the host picks by grid balance: 36 864 x 256 outputs are
+    576 tiles of 128 rows = two rounds of 512 resident blocks, 462 tiles of 160 rows = one)."""
+    M, N, K = shape
+    x, w, g = _lin_inputs(M, N, K, "bf16", M + N)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    xd, wd = x.to(DEV), w.to(DEV)
+    L().ttv_debug_set(128 if tile == 160 else 256)
+    try:
+        _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, None, None, y.data_ptr(), N, M, N, K, _lib.dtype_code(torch.bfloat16), S()), "linear")
+        torch.cuda.synchronize()
+    finally:
+        L().ttv_debug_set(0)
+    assert_close(y.float(), x.double() @ w.double().T, "bf16")
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(300, 256, 768), (129, 768, 256), (64, 8, 256), (1, 256, 704), (513, 256, 1376)])
 def test_linear_bias_scalar(dt, shape):

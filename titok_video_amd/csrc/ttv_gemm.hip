@@ -201,17 +201,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int EPI, bool GATHER = false>
+// NJ = 16-token fragments per wave: the token tile is 32 NJ rows (128 or 160).  The 160-row variant exists for grid balance:
+// with 2 resident blocks per CU (512 slots) a 36 864-token, 256-feature GEMM is 576 tiles of 128 tokens = two rounds with the
+// second one 12 % full, but 462 tiles of 160 tokens = one round (host picks the cheaper of the two).  The fifth staging chunk /
+// fragment is written out with named scalars like the other four: with arrays hipcc keeps the staging registers in scratch and
+// turns the global loads into flat loads (measured: +15 % on the whole training step).
+template <int EPI, bool GATHER = false, int NJ = 4>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
   constexpr int FT = DUAL ? 64 : TF;  // output features per block
-  __shared__ uint4 lds[2][2][TF * 8];  // [buffer][operand: 0 = w, 1 = x][row*8 + swizzled chunk], 64 KiB
+  constexpr int TTK = 32 * NJ;        // tokens per block
+  constexpr bool X5 = NJ == 5;
+  static_assert(NJ == 4 || NJ == 5, "token tile is 128 or 160 rows");
+  __shared__ uint4 lds[2][(TF + TTK) * 8];  // [buffer][w rows 0..127 | x rows][row*8 + swizzled chunk], 64 / 72 KiB
+#define LDSW(buf_, idx_) lds[buf_][idx_]
+#define LDSX(buf_, idx_) lds[buf_][TF * 8 + (idx_)]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wf = wave & 1, wt = wave >> 1;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int fbase = (tile % n_ftiles) * FT;
-  const int tbase = (tile / n_ftiles) * TT;
+  const int tbase = (tile / n_ftiles) * TTK;
 
   const bf16_t* W = (const bf16_t*)p.w;
   const bf16_t* X = (const bf16_t*)p.x;
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
   // per-thread staging: 4 chunks (16 B) of each operand per k-tile; chunk = tid + 256*i -> row = chunk>>3, kc = chunk&7
   const int srow = tid >> 3, skc = tid & 7;
   const bf16_t* wp0; const bf16_t* wp1; const bf16_t* wp2; const bf16_t* wp3;
-  const bf16_t* xp0; const bf16_t* xp1; const bf16_t* xp2; const bf16_t* xp3;
+  const bf16_t* xp0; const bf16_t* xp1; const bf16_t* xp2; const bf16_t* xp3; const bf16_t* xp4 = nullptr;
   {
     auto wrow = [&](int row) {
       int wr;
@@ -235,13 +245,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     };
     wp0 = wrow(srow); wp1 = wrow(srow + 32); wp2 = wrow(srow + 64); wp3 = wrow(srow + 96);
     xp0 = xrow(srow); xp1 = xrow(srow + 32); xp2 = xrow(srow + 64); xp3 = xrow(srow + 96);
+    if (X5) xp4 = xrow(srow + 128);
   }
   // GATHER (encoder proj_in, blocks.py:91-93 + utils.py:26-34): GEMM row t is patch t and its K = (c, pt, ph, pw) vector is
   // read straight from the clip: a 16-byte chunk = the pw = 8 pixels of one (c, ipt, iph) image row of the patch
-  PatchDst gx[4];
+  PatchDst gx[NJ];
   if (GATHER) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NJ; ++i) {
       int t = tbase + srow + 32 * i;
       t = t < p.M ? t : p.M - 1;
       const int ci = p.row_seq[p.patch_rows[t]];
@@ -264,14 +275,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
   const int li1 = (srow + 32) * 8 + (skc ^ (((srow + 32) >> 1) & 7));
   const int li2 = (srow + 64) * 8 + (skc ^ (((srow + 64) >> 1) & 7));
   const int li3 = (srow + 96) * 8 + (skc ^ (((srow + 96) >> 1) & 7));
+  const int li4 = (srow + 128) * 8 + (skc ^ (((srow + 128) >> 1) & 7));
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 sw0, sw1, sw2, sw3, sx0, sx1, sx2, sx3;
+  uint4 sw0, sw1, sw2, sw3, sx0, sx1, sx2, sx3, sx4;
   const uint4 zero4 = {0u, 0u, 0u, 0u};
 #define GLOAD(k0)                                                                   \
   do {                                                                              \
@@ -284,11 +296,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     sx1 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(1, k0) : xp1 + (k0)) : zero4; \
     sx2 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(2, k0) : xp2 + (k0)) : zero4; \
     sx3 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(3, k0) : xp3 + (k0)) : zero4; \
+    if (X5) sx4 = ok__ ? *reinterpret_cast<const uint4*>(GATHER ? GXPTR(NJ - 1, k0) : xp4 + (k0)) : zero4; \
   } while (0)
 #define LSTORE(buf)                                                                 \
   do {                                                                              \
-    lds[buf][0][li0] = sw0; lds[buf][0][li1] = sw1; lds[buf][0][li2] = sw2; lds[buf][0][li3] = sw3; \
-    lds[buf][1][li0] = sx0; lds[buf][1][li1] = sx1; lds[buf][1][li2] = sx2; lds[buf][1][li3] = sx3; \
+    LDSW(buf, li0) = sw0; LDSW(buf, li1) = sw1; LDSW(buf, li2) = sw2; LDSW(buf, li3) = sw3; \
+    LDSX(buf, li0) = sx0; LDSX(buf, li1) = sx1; LDSX(buf, li2) = sx2; LDSX(buf, li3) = sx3; \
+    if (X5) LDSX(buf, li4) = sx4;                                                   \
   } while (0)
 
   const int l15 = lane & 15, kq = lane >> 4;
@@ -301,19 +315,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
     if (kt + 1 < nk) GLOAD((kt + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
+      bf16x8 a[4], b[NJ];
       const int kc = ks * 4 + kq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
-        const int brow = wt * 64 + i * 16 + l15;
-        a[i] = __builtin_bit_cast(bf16x8, lds[buf][0][arow * 8 + (kc ^ ((arow >> 1) & 7))]);
-        b[i] = __builtin_bit_cast(bf16x8, lds[buf][1][brow * 8 + (kc ^ ((brow >> 1) & 7))]);
+        a[i] = __builtin_bit_cast(bf16x8, LDSW(buf, arow * 8 + (kc ^ ((arow >> 1) & 7))));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int brow = wt * (16 * NJ) + j * 16 + l15;
+        b[j] = __builtin_bit_cast(bf16x8, LDSX(buf, brow * 8 + (kc ^ ((brow >> 1) & 7))));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) LSTORE(buf ^ 1);
     __syncthreads();
@@ -321,25 +338,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
 #undef GLOAD
 #undef LSTORE
 #undef GXPTR
+#undef LDSW
+#undef LDSX
 
-  int tok[4];
+  int tok[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tok[j] = tbase + wt * 64 + j * 16 + l15;
+  for (int j = 0; j < NJ; ++j) tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
   if (DUAL) {
     int feat[2];
-    f32x4 ax[2][4], ag[2][4];
+    f32x4 ax[2][NJ], ag[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
+      for (int j = 0; j < NJ; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
     }
-    epilogue_tile<EPI, bf16_t, 2, 4>(p, tok, feat, ax, ag, kq);
+    epilogue_tile<EPI, bf16_t, 2, NJ>(p, tok, feat, ax, ag, kq);
   } else {
     int feat[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
-    epilogue_tile<EPI, bf16_t, 4, 4>(p, tok, feat, acc, acc, kq);
+    epilogue_tile<EPI, bf16_t, 4, NJ>(p, tok, feat, acc, acc, kq);
   }
 }
 
@@ -892,8 +911,14 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
   }
   if (dtype == TTV_BF16) {
     const int ft = (EPI == EPI_GEGLU) ? 64 : TF;
-    const int nf = ttv_cdiv(d.N, ft), nt = ttv_cdiv(d.M, TT);
-    hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    const int nf = ttv_cdiv(d.N, ft), nt = ttv_cdiv(d.M, TT), nt160 = ttv_cdiv(d.M, 160);
+    // rounds of 512 resident blocks x tile height: the 160-token tile when it saves a (mostly empty) round
+    const int force_tt = (d.debug & 128) ? 160 : (d.debug & 256) ? 128 : 0;   // diagnostics / tests (ttv_debug_set)
+    const long cost128 = (long)ttv_cdiv(nf * nt, 512) * 128, cost160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
+    if ((cost160 < cost128 && force_tt != 128) || force_tt == 160)
+      hipLaunchKernelGGL((k_gemm_bf16<EPI, false, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+    else
+      hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
   } else {
     const int nf = ttv_cdiv(d.N, F_TF), nt = ttv_cdiv(d.M, F_TT);
     hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
@@ -941,8 +966,13 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
     case EPI_STORE:
       if (a.gather) {
-        const int nf = ttv_cdiv(d.N, TF), nt = ttv_cdiv(d.M, TT);
-        hipLaunchKernelGGL((k_gemm_bf16<EPI_STORE, true>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+        const int nf = ttv_cdiv(d.N, TF), nt = ttv_cdiv(d.M, TT), nt160 = ttv_cdiv(d.M, 160);
+        const int force_tt = (d.debug & 128) ? 160 : (d.debug & 256) ? 128 : 0;
+        const long cost128 = (long)ttv_cdiv(nf * nt, 512) * 128, cost160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
+        if ((cost160 < cost128 && force_tt != 128) || force_tt == 160)
+          hipLaunchKernelGGL((k_gemm_bf16<EPI_STORE, true, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+        else
+          hipLaunchKernelGGL((k_gemm_bf16<EPI_STORE, true>), dim3(nf * nt), dim3(256), 0, s, d, nf);
         TTV_CHECK_LAUNCH("gemm_gather");
         return TTV_OK;
       }

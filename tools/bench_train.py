@@ -8,6 +8,9 @@ from titok_video_amd.model.titok import TiTok
 from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
 from titok_video_amd.train import freeze_python_gc, make_optimizer, training_step
 B = int(os.environ.get("B", "32"))
+if os.environ.get("TTV_DEBUG"):   # diagnostics bits of ttv_debug_set (A/B runs on one box)
+    from titok_video_amd import _lib
+    _lib.lib().ttv_debug_set(int(os.environ["TTV_DEBUG"]))
 cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5], encoder_size="tiny", decoder_size="tiny")))
 m = TiTok(cfg); m.load_state_dict(seeded_titok_state(0)); m = m.to("cuda:0", torch.bfloat16).train()
 clips = synthetic_clips([(16, 128, 128)] * B, seed=1, dtype=torch.bfloat16, device="cuda:0")

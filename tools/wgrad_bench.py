@@ -31,3 +31,24 @@ for name, N, K in (("w3", 256, 704), ("w12", 1408, 256), ("out_proj", 256, 256),
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     print(f"wgrad {name:9s} N={N:5d} K={K:4d}  {us:7.1f} us  {2.0 * L * N * K / us / 1e6:7.1f} TFLOP/s")
+
+# the dX GEMMs of the same layers (general-K kernel, 256 output features): grid balance decides the token-tile height
+for name, N, K in (("dX qkv", 256, 768), ("dX w12", 256, 1408), ("fwd w3", 256, 704)):
+    x = torch.randn(L, K, device=DEV).bfloat16()
+    w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+    y = torch.empty(L, N, device=DEV, dtype=torch.bfloat16)
+    for flag, tag in ((256, "tile 128"), (128, "tile 160"), (0, "auto")):
+        lib.ttv_debug_set(flag)
+        fn = lambda: _lib.check(lib.ttv_linear(x.data_ptr(), K, w.data_ptr(), K, None, None, y.data_ptr(), N, L, N, K, _lib.dtype_code(torch.bfloat16), S), "linear")
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        print(f"{name:8s} N={N:4d} K={K:4d} {tag:9s} {us:7.1f} us  {2.0 * L * N * K / us / 1e6:7.1f} TFLOP/s")
+    lib.ttv_debug_set(0)
