@@ -1170,18 +1170,19 @@ __device__ __forceinline__ bf16x8 pack_pair(f32x4 lo, f32x4 hi) {
 // The block's K / V rows are the B operands of S and dP in every step: their fragments are loaded from global once and stay
 // in registers.  The streamed Q / dO tiles (and the lse / delta rows) arrive by LDS-DMA into two stages, one step ahead: one
 // barrier per step, nothing of the staging passes through VGPRs.
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         const int* __restrict__ cu, const int* __restrict__ blocks,
-                                                         bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale, const float* __restrict__ rope_cs) {
-  __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];   // Q stages 0/1, dO stages 0/1; the final cross-wave sum reuses it
-  __shared__ __attribute__((aligned(16))) float ls[2][2][64];     // [stage][lse | delta][query]
+// tiles: 4 x 512 uint4 (Q stages 0/1, dO stages 0/1; the final cross-wave sum reuses it); ls: [stage][lse | delta][query]
+__device__ __forceinline__ void attn_bwd_dkv_block(uint4* tiles, float (*ls)[2][64], const int bx, const int by,
+                                                   const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                   const int* __restrict__ cu, const int* __restrict__ blocks,
+                                                   bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale,
+                                                   const float* __restrict__ rope_cs) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
-  const int seq = blocks[2 * blockIdx.x], key0 = blocks[2 * blockIdx.x + 1];
-  const int kvh = blockIdx.y;
+  const int seq = blocks[2 * bx], key0 = blocks[2 * bx + 1];
+  const int kvh = by;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int d_model = hq * 64, gqa = hkv * 64, rep = hq / hkv;
   const bf16_t* base = qkvg + (size_t)s0 * ld;
@@ -1320,17 +1321,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(const bf16_t* __restric
 // Each wave accumulates all 64 d for its 32 queries over its 32 keys of every block; the two key halves are summed at the end.
 // Mirror image of the kernel above: the block's Q / dO fragments (B operands) and its lse / delta live in registers, the K / V
 // tiles stream through two LDS-DMA stages.
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
-                                                        const float* __restrict__ lse, const float* __restrict__ delta,
-                                                        const int* __restrict__ cu, const int* __restrict__ blocks,
-                                                        bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale, const float* __restrict__ rope_cs) {
-  __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];   // K stages 0/1, V stages 0/1; the final cross-wave sum reuses it
+// tiles: 4 x 512 uint4 (K stages 0/1, V stages 0/1; the final cross-wave sum reuses it)
+__device__ __forceinline__ void attn_bwd_dq_block(uint4* tiles, const int bx, const int by,
+                                                  const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                  const int* __restrict__ cu, const int* __restrict__ blocks,
+                                                  bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale,
+                                                  const float* __restrict__ rope_cs) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
-  const int seq = blocks[2 * blockIdx.x], q0 = blocks[2 * blockIdx.x + 1];
-  const int h = blockIdx.y;
+  const int seq = blocks[2 * bx], q0 = blocks[2 * bx + 1];
+  const int h = by;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int d_model = hq * 64, gqa = hkv * 64, kvh = h / (hq / hkv);
   const bf16_t* base = qkvg + (size_t)s0 * ld;
@@ -1439,6 +1442,27 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(const bf16_t* __restrict
     }
 }
 
+// Both halves of the attention backward in ONE grid ("horizontal fusion"): they are independent (same inputs, disjoint output
+// columns), and launched one after the other each leaves a tail - at the benchmark batch dK/dV is 1152 blocks on 768 resident
+// slots (second round half empty) and dQ 2304 blocks on 1024 (third round a quarter full).  The long blocks come first (dK/dV: 36
+// steps each), the short ones (dQ: 18 steps) fill in behind them, so only the very end of the grid runs below full occupancy.
+__global__ __launch_bounds__(256, 2) void k_attn_bwd(const bf16_t* __restrict__ qkvg, int ld, const bf16_t* __restrict__ dout, int ldd,
+                                                     const float* __restrict__ lse, const float* __restrict__ delta,
+                                                     const int* __restrict__ cu, const int* __restrict__ blocks, int n_blocks,
+                                                     bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale,
+                                                     const float* __restrict__ rope_cs) {
+  __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];
+  __shared__ __attribute__((aligned(16))) float ls[2][2][64];
+  const int n_dkv = n_blocks * hkv;
+  int b = blockIdx.x;
+  if (b < n_dkv) {
+    attn_bwd_dkv_block(tiles, ls, b % n_blocks, b / n_blocks, qkvg, ld, dout, ldd, lse, delta, cu, blocks, dqkvg, ldg, hq, hkv, scale, rope_cs);
+  } else {
+    b -= n_dkv;
+    attn_bwd_dq_block(tiles, b % n_blocks, b / n_blocks, qkvg, ld, dout, ldd, lse, delta, cu, blocks, dqkvg, ldg, hq, hkv, scale, rope_cs);
+  }
+}
+
 // blocks64: device int32 [n,2] = (sequence, first row) for 64-row blocks; row_seq: device int32 [L] sequence of every row
 // (fp32 path); dkv_scratch: fp32 [L, 2g] zeroed by this function (fp32 path only).
 int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
@@ -1451,10 +1475,9 @@ int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const v
   else hipLaunchKernelGGL((k_attn_delta<float>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const float*)dout, ldd, (const float*)o, ldo, delta, total_rows, hq);
   TTV_CHECK_LAUNCH("attn_delta");
   if (dt == TTV_BF16) {
-    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(n_blocks64, hkv), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs);
-    TTV_CHECK_LAUNCH("attn_bwd_dkv");
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(n_blocks64, hq), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu, blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs);
-    TTV_CHECK_LAUNCH("attn_bwd_dq");
+    hipLaunchKernelGGL(k_attn_bwd, dim3(n_blocks64 * (hkv + hq)), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu,
+                       blocks64, n_blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs);
+    TTV_CHECK_LAUNCH("attn_bwd");
   } else {
     TTV_CHECK_ARG(dkv_scratch && row_seq, "attention_bwd: fp32 path needs scratch and row map");
     (void)hipMemsetAsync(dkv_scratch, 0, (size_t)total_rows * 2 * gqa * sizeof(float), s);
