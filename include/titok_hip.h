@@ -125,9 +125,12 @@ int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, 
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
  * Non-causal, block-diagonal over cu_seqlens (device int32 [n_seq+1]), GQA, softmax scale head_dim^-0.5.
- * qblocks: device int32 [n_qblocks,4] work table = (sequence id, first query row within the sequence, q-head, 0), one
- * entry per 128-query block per q-head; sequence id -1 = padding.  The host orders it so that entries i, i+8, i+16, ...
- * (one XCD under round-robin dispatch) share a (sequence, kv-head): its K/V are then fetched into one L2 only.
+ * qblocks: device int32 [n_qblocks,4] work table = (sequence id, first query row within the sequence, q-head, mode), one
+ * entry per query block per q-head; sequence id -1 = padding.  mode 0: 128 query rows; mode 1 ("half item"): 64 query rows
+ * with the key range split between the two wave pairs of the block and merged at the end - about half the duration of a
+ * full item, used by the host to fill the tail of the grid at a finer grain.  The host orders the table so that
+ * entries i, i+8, i+16, ... (one XCD under round-robin dispatch) share a (sequence, kv-head): its K/V are then fetched into
+ * one L2 only; half items come last.
  * If gate_mul == 0 the raw attention output is written. */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream);

@@ -341,7 +341,8 @@ def test_layer_tail_fused(M, keel, back):
 @pytest.mark.parametrize("case", [([(4, 16, 16)], [1]), ([(8, 32, 48), (4, 8, 24), (16, 64, 64)], [5, 3, 128]),
                                   ([(16, 128, 128)], [128]), ([(4, 8, 8), (4, 8, 8)], [0, 63])])
 @pytest.mark.parametrize("heads", [(4, 2), (12, 4)])
-def test_attention_varlen_gqa_gate(dt, case, heads):
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_varlen_gqa_gate(dt, case, heads, split):
     shapes, counts = case
     plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
     hq, hkv = heads
@@ -354,7 +355,8 @@ def test_attention_varlen_gqa_gate(dt, case, heads):
     out = torch.empty(plan.total_rows, d, dtype=DT[dt], device=DEV)
     xd = qkvg.to(DEV)
     for gate in (1, 0):
-        tab = plan.attention_table(hq, hkv)
+        tab = plan.attention_table(hq, hkv, split)     # 128-query items / 64-query half items (key range split in-block)
+        out.fill_(float("nan"))
         _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
                                      tab.shape[0], hq, hkv, 64, gate, _lib.dtype_code(DT[dt]), S()), "attention")
         f = qkvg.float()
@@ -366,7 +368,8 @@ def test_attention_varlen_gqa_gate(dt, case, heads):
         assert_close(out.float(), ref, dt, scale=2.0 if dt == "bf16" else 5.0)
 
 
-def test_attention_online_softmax_rescale_branch():
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_online_softmax_rescale_branch(split):
     """Force the running max to jump at a late key tile (spike one key against every query)."""
     plan = BatchPlan([(8, 32, 32)], [7], (4, 8, 8), DEV)   # S = 39 ... use a longer one
     plan = BatchPlan([(16, 64, 64)], [9], (4, 8, 8), DEV)  # S = 265 -> 5 key tiles
@@ -379,7 +382,7 @@ def test_attention_online_softmax_rescale_branch():
     x = x.to(torch.bfloat16)
     out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
     xd = x.to(DEV)
-    tab = plan.attention_table(hq, hkv)
+    tab = plan.attention_table(hq, hkv, split)
     _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
                                  tab.shape[0], hq, hkv, 64, 0, _lib.TTV_BF16, S()), "attention")
     f = x.float()

@@ -27,21 +27,39 @@ def test_plan_tables_match_oracle_metadata():
     assert plan.latent_rows_dev.tolist() == rows[mask].tolist()
     assert plan.patch_rows_dev.tolist() == rows[~mask].tolist()
     for hq, hkv in [(4, 2), (12, 4)]:
-        tab = plan.attention_table(hq, hkv).tolist()
-        covered = []
-        unit_xcd = {}
-        for i, (b, q0, head, _) in enumerate(tab):
-            if b < 0:
-                continue                                   # padding entry of the XCD-interleaved order
-            s_len = cu[b + 1] - cu[b]
-            assert q0 % 128 == 0 and q0 < s_len and 0 <= head < hq
-            covered += [(b, head, r) for r in range(q0, min(q0 + 128, s_len))]
-            unit = (b, head // (hq // hkv))
-            assert unit_xcd.setdefault(unit, i % 8) == i % 8    # all blocks sharing K/V sit on one XCD slot
-        assert len(covered) == cu[-1] * hq == len(set(covered))   # every (row, q-head) exactly once
-        assert plan.batch_for(hq, hkv).n_qblocks == len(tab)
-    desc = plan.clip_desc_dev.view(-1, 8)
-    assert desc[:, 6].tolist() == [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]
+        for split in (None, False, True):
+            tab = plan.attention_table(hq, hkv, split).tolist()
+            covered = []
+            unit_xcd = {}
+            seen_half = [False] * 8
+            for i, (b, q0, head, mode) in enumerate(tab):
+                if b < 0:
+                    continue                                   # padding entry of the XCD-interleaved order
+                s_len = cu[b + 1] - cu[b]
+                rows = 64 if mode else 128
+                assert mode in (0, 1) and q0 % rows == 0 and q0 < s_len and 0 <= head < hq
+                assert mode or not seen_half[i % 8]            # half items come after the full ones of their XCD list
+                seen_half[i % 8] |= bool(mode)
+                assert split is not False or mode == 0
+                assert split is not True or mode == 1
+                covered += [(b, head, r) for r in range(q0, min(q0 + rows, s_len))]
+                unit = (b, head // (hq // hkv))
+                assert unit_xcd.setdefault(unit, i % 8) == i % 8    # all blocks sharing K/V sit on one XCD slot
+            assert len(covered) == cu[-1] * hq == len(set(covered))   # every (row, q-head) exactly once
+        assert plan.batch_for(hq, hkv).n_qblocks == len(plan.attention_table(hq, hkv))
+
+
+def test_attention_table_halves_the_last_third_of_each_sequence():
+    """Benchmark batch: 32 clips x 9 query blocks x 4 heads = 1152 items -> blocks 6..8 of every sequence become half items:
+    768 full + 768 half.  The choice depends on the sequence only."""
+    plan = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu")
+    tab = plan.attention_table(4, 2)
+    real = tab[tab[:, 0] >= 0]
+    assert int((real[:, 3] == 0).sum()) == 768 and int((real[:, 3] == 1).sum()) == 768
+    one = BatchPlan([(16, 128, 128)], [128], (4, 8, 8), "cpu").attention_table(4, 2)
+    one = one[one[:, 0] >= 0]
+    mine = real[real[:, 0] == 7][:, 1:]
+    assert sorted(map(tuple, mine.tolist())) == sorted(map(tuple, one[:, 1:].tolist()))   # same items alone and in the batch
 
 
 def test_plan_rope_table_is_reference_bits():

@@ -2,7 +2,8 @@
 // (replaces flash_attn_varlen_func at reference model/base/transformer.py:100 and the gate at :103).
 //
 // bf16 kernel (head_dim 64).  One workgroup = 4 waves = 128 query rows of one (sequence, q-head); each wave owns
-// 32 queries.  K/V tiles of 64 keys are register-staged into double-buffered, XOR-swizzled LDS.
+// 32 queries.  K/V tiles of 64 keys are staged by LDS-DMA into double-buffered, XOR-swizzled LDS (124 VGPRs: 4 blocks per CU).
+// "Half items" (work-table mode 1): 64 query rows, wave pairs split the key range and merge their (O, m, l) at the end.
 //   S^T = K Q^T   : mfma_f32_32x32x16_bf16 with the KEY on the MFMA row and the QUERY on the lane (col = lane&31),
 //                   so a lane holds 32 scores of ONE query: row max / row sum are in-lane plus one xor-32 exchange.
 //   O^T = V^T P^T : the S^T accumulator registers, packed to bf16, ARE the B operand (k order
@@ -37,6 +38,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   const int r = lane & 31, h = lane >> 5;
   // work table entry: (sequence, first query row, q-head); sequence < 0 = padding entry of the XCD-interleaved order
   const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
+  // mode 1 = "half item": 64 query rows; waves 0,1 take the first half of the key range, waves 2,3 the second half (32-key
+  // tiles, one per wave and step) and the two partial (O, m, l) states are merged through LDS at the end.  A half item takes
+  // about 0.6 of the time of a full one; the host puts them at the end of the table where they fill the tail of the grid
+  // (plan.attention_table).
+  const int mode = qblocks[4 * blockIdx.x + 3];
   if (seq < 0) return;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int kvh = head / rep;
@@ -46,32 +52,41 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   const bf16_t* vbase = kbase + gqa;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[query r][16*ks + 8h + 0..7]
-  const int qrow = q0 + wave * 32 + r;
+  const int qrow = q0 + (mode ? (wave & 1) : wave) * 32 + r;
   const int qrc = qrow < S ? qrow : S - 1;
   bf16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8);
 
-  // staging assignment: 2 chunks (16 B) of K and 2 of V per thread per tile: key = (tid>>3) + 32*i, chunk = tid&7
-  const int skey = tid >> 3, scc = tid & 7;
-  const int kidx0 = skey * 8 + (scc ^ ((skey >> 1) & 7));
-  const int kidx1 = (skey + 32) * 8 + (scc ^ (((skey + 32) >> 1) & 7));
-  const int vidx0 = skey * 8 + (scc ^ (((skey >> 1) & 1) << 2));
-  const int vidx1 = (skey + 32) * 8 + (scc ^ ((((skey + 32) >> 1) & 1) << 2));
-  uint4 sk0, sk1, sv0, sv1;
-#define GLOAD(kt_)                                                                       \
-  do {                                                                                   \
-    int k0__ = (kt_) * KB + skey, k1__ = k0__ + 32;                                      \
-    k0__ = k0__ < S ? k0__ : S - 1;                                                      \
-    k1__ = k1__ < S ? k1__ : S - 1;                                                      \
-    sk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)k0__ * ld + scc * 8);          \
-    sk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)k1__ * ld + scc * 8);          \
-    sv0 = *reinterpret_cast<const uint4*>(vbase + (size_t)k0__ * ld + scc * 8);          \
-    sv1 = *reinterpret_cast<const uint4*>(vbase + (size_t)k1__ * ld + scc * 8);          \
+  // K / V tiles are staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write, nothing to wait for before
+  // the barrier except the DMA itself).  Instruction i of wave w covers tile rows 8 (2w + i) .. + 7: lane >> 3 picks the row,
+  // lane & 7 the 16-byte LDS chunk; the DMA writes lanes linearly, so the XOR swizzles are applied on the global side (the lane
+  // fetches the chunk that belongs at its LDS position): K chunk c holds global chunk c ^ ((row >> 1) & 7), V chunk c holds
+  // c ^ (((row >> 1) & 1) << 2).  Rows past the sequence end re-fetch its last row (masked in the scores).
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t kl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&kl[0][0];
+  const uint32_t vl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&vl[0][0];
+  const int drow0 = (wave_s * 2) * 8 + (lane >> 3), drow1 = drow0 + 8;
+  const int kc0 = ((lane & 7) ^ ((drow0 >> 1) & 7)) * 8, kc1 = ((lane & 7) ^ ((drow1 >> 1) & 7)) * 8;
+  const int vc0 = ((lane & 7) ^ (((drow0 >> 1) & 1) << 2)) * 8, vc1 = ((lane & 7) ^ (((drow1 >> 1) & 1) << 2)) * 8;
+#define DMA16(voff_, base_, dst_)                                                                                \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                 \
   } while (0)
-#define LSTORE(buf_)                                                                     \
-  do {                                                                                   \
-    kl[buf_][kidx0] = sk0; kl[buf_][kidx1] = sk1; vl[buf_][vidx0] = sv0; vl[buf_][vidx1] = sv1; \
+  // tile rows 0..31 <- keys base0_ + row, rows 32..63 <- keys base1_ + (row - 32)   (waves 0,1 stage the first, 2,3 the second half)
+#define DMA2(base0_, base1_, buf_)                                                                               \
+  do {                                                                                                           \
+    const int rb__ = wave_s < 2 ? (base0_) : (base1_) - 32;                                                      \
+    int g0__ = rb__ + drow0, g1__ = rb__ + drow1;                                                                \
+    g0__ = g0__ < S ? g0__ : S - 1;                                                                              \
+    g1__ = g1__ < S ? g1__ : S - 1;                                                                              \
+    const uint32_t dk__ = kl_lds + (buf_) * (KB * 128) + wave_s * 2048, dv__ = vl_lds + (buf_) * (KB * 128) + wave_s * 2048; \
+    DMA16((uint32_t)(g0__ * ld + kc0) * 2u, kbase, dk__);                                                        \
+    DMA16((uint32_t)(g1__ * ld + kc1) * 2u, kbase, dk__ + 1024);                                                 \
+    DMA16((uint32_t)(g0__ * ld + vc0) * 2u, vbase, dv__);                                                        \
+    DMA16((uint32_t)(g1__ * ld + vc1) * 2u, vbase, dv__ + 1024);                                                 \
   } while (0)
 
   f32x16 o_acc[2];
@@ -100,12 +115,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
-  GLOAD(0);
-  LSTORE(0);
-  __syncthreads();
+  if (mode == 0) {
+  DMA2(0, 32, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) GLOAD(kt + 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile kt has landed
+    __syncthreads();                      // tile complete; every wave is done with the other stage
+    if (kt + 1 < nkt) DMA2((kt + 1) * KB, (kt + 1) * KB + 32, buf ^ 1);
     const char* kt_lds = kbase_lds + buf * (KB * 128);
     const char* vt_lds = vbase_lds + buf * (KB * 128);
 
@@ -204,11 +220,114 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
     }
 #undef VFRAG
 
-    if (kt + 1 < nkt) LSTORE(buf ^ 1);
-    __syncthreads();
   }
-#undef GLOAD
-#undef LSTORE
+  } else {
+    // ================= half item: 64 queries, the key range split between the two wave pairs =================
+    const int kh = __builtin_amdgcn_readfirstlane(wave >> 1);
+    const int n32 = (S + 31) >> 5, n_half = (n32 + 1) >> 1;      // 32-key tiles; pair 0: [0, n_half), pair 1: [n_half, n32)
+    DMA2(0, n_half * 32, 0);
+    for (int st = 0; st < n_half; ++st) {
+      const int buf = st & 1;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      if (st + 1 < n_half) DMA2((st + 1) * 32, (n_half + st + 1) * 32, buf ^ 1);
+      const int key0 = (kh ? n_half + st : st) * 32;
+      if (key0 < S) {   // wave-uniform; pair 1 may run out of tiles one step early
+        // rows 32 kh .. 32 kh + 31 of the staged tile are this pair's keys
+        const char* kt_lds = kbase_lds + buf * (KB * 128) + kh * 4096;
+        const char* vt_lds = vbase_lds + buf * (KB * 128) + kh * 4096;
+        f32x16 sc;
+        {
+          bf16x8 kf[4];
+          kf[0] = *reinterpret_cast<const bf16x8*>(kt_lds + koff0);
+          kf[1] = *reinterpret_cast<const bf16x8*>(kt_lds + koff1);
+          kf[2] = *reinterpret_cast<const bf16x8*>(kt_lds + koff2);
+          kf[3] = *reinterpret_cast<const bf16x8*>(kt_lds + koff3);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks ? sc : zero16, 0, 0, 0);
+        }
+        if (key0 + 32 > S) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (key >= S) sc[e] = -INFINITY;
+          }
+        }
+        float mx = sc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mc = m_new * c_exp;
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          sc[e] = __builtin_amdgcn_exp2f(fmaf(sc[e], c_exp, -mc));
+          psum += sc[e];
+        }
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+          l_run *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+          m_run = m_new;
+        }
+        l_run += psum;
+#define PFRAGH(sp_)                                                                                                \
+  ((bf16x8){(bf16_t)sc[8 * sp_ + 0], (bf16_t)sc[8 * sp_ + 1], (bf16_t)sc[8 * sp_ + 2], (bf16_t)sc[8 * sp_ + 3],      \
+            (bf16_t)sc[8 * sp_ + 4], (bf16_t)sc[8 * sp_ + 5], (bf16_t)sc[8 * sp_ + 6], (bf16_t)sc[8 * sp_ + 7]})
+        const bf16x8 pf0 = PFRAGH(0), pf1 = PFRAGH(1);
+#undef PFRAGH
+#define VFRAGH(dt_, sp_)                                                                                           \
+  ({                                                                                                               \
+    const char* vb__ = vt_lds + ((dt_) == 0 ? voff_d0 : voff_d1) + (sp_) * 2048;                                   \
+    const bf16x4 lo__ = lds_read_tr16(vb__), hi__ = lds_read_tr16(vb__ + 1024);                                    \
+    (bf16x8){lo__[0], lo__[1], lo__[2], lo__[3], hi__[0], hi__[1], hi__[2], hi__[3]};                              \
+  })
+        const bf16x8 v00 = VFRAGH(0, 0), v01 = VFRAGH(0, 1), v10 = VFRAGH(1, 0), v11 = VFRAGH(1, 1);
+#undef VFRAGH
+        o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v00, pf0, o_acc[0], 0, 0, 0);
+        o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v10, pf0, o_acc[1], 0, 0, 0);
+        o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v01, pf1, o_acc[0], 0, 0, 0);
+        o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v11, pf1, o_acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // every wave is done with the tiles: they become the exchange buffer
+    // merge the two key halves: pair 1 hands its state to pair 0 (same query rows, same lane layout) through the K / V tiles
+    f32x4* xo = reinterpret_cast<f32x4*>(&kl[0][0]);      // [qg][8][64 lanes] float4 = 16 KB
+    float* xm = reinterpret_cast<float*>(&vl[0][0]);      // [qg][m | l][64 lanes]
+    const int qg = wave & 1;
+    if (kh == 1) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          xo[(qg * 8 + dt * 4 + g) * 64 + lane] = (f32x4){o_acc[dt][4 * g], o_acc[dt][4 * g + 1], o_acc[dt][4 * g + 2], o_acc[dt][4 * g + 3]};
+      xm[(qg * 2 + 0) * 64 + lane] = m_run;
+      xm[(qg * 2 + 1) * 64 + lane] = l_run;
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    {
+      const float m1 = xm[(qg * 2 + 0) * 64 + lane], l1 = xm[(qg * 2 + 1) * 64 + lane];
+      const float m_all = fmaxf(m_run, m1);
+      const float a0 = __builtin_amdgcn_exp2f((m_run - m_all) * c_exp), a1 = __builtin_amdgcn_exp2f((m1 - m_all) * c_exp);
+      l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o1 = xo[(qg * 8 + dt * 4 + g) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o_acc[dt][4 * g + e] = o_acc[dt][4 * g + e] * a0 + o1[e] * a1;
+        }
+      m_run = m_all;
+    }
+  }
+#undef DMA2
+#undef DMA16
 
   // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -251,6 +370,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
   const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
   if (seq < 0) return;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int q_lim = (qblocks[4 * blockIdx.x + 3] && q0 + 64 < S) ? q0 + 64 : S;   // half item: 64 query rows (see the bf16 kernel)
   const int kvh = head / rep;
   const float* qbase = qkvg + (size_t)s0 * ld + head * 64;
   const float* gbase = qkvg + (size_t)s0 * ld + d_model + head * 64;
@@ -302,8 +422,8 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
 #pragma unroll
   for (int qi = 0; qi < 32; ++qi) {
     const int qrow = q0 + wave * 32 + qi;
-    if (lse_out && qrow < S && lane == 0) lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run[qi] + logf(l_run[qi]);
-    if (qrow < S) {
+    if (lse_out && qrow < q_lim && lane == 0) lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run[qi] + logf(l_run[qi]);
+    if (qrow < q_lim) {
       float v = o[qi] / l_run[qi];
       if (GATE) {
         const float g = gbase[(size_t)qrow * ld + lane];

@@ -13,7 +13,8 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import math
-from typing import List, Sequence, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -21,6 +22,7 @@ import torch
 from . import _lib
 
 QBLOCK = 128  # query rows per attention workgroup (csrc/ttv_attn.hip QB)
+ATTN_SLOTS = 1024  # attention blocks resident at once: 4 per CU (124 VGPRs, 32 KB LDS) x 256 CUs (MI355X)
 
 
 @functools.lru_cache(maxsize=8)
@@ -147,25 +149,48 @@ class BatchPlan:
         self._offs = offs
         self._attn = {}
 
-    def attention_table(self, q_heads: int, kv_heads: int) -> torch.Tensor:
-        """int32 [n,4] attention work table (sequence, first query row, q-head, 0) for this batch, XCD-aware.
+    def attention_table(self, q_heads: int, kv_heads: int, split: Optional[bool] = None) -> torch.Tensor:
+        """int32 [n,4] attention work table (sequence, first query row, q-head, mode) for this batch, XCD-aware.
 
         Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8 share an XCD - a speed
         assumption only, never correctness).  All blocks of one (sequence, kv-head) unit re-read the same K/V, so units
         are distributed over 8 lists (greedy by block count) and the lists are interleaved: entry i goes to list i % 8.
-        Shorter lists are padded with sequence = -1 entries (the kernel returns immediately)."""
-        key = (int(q_heads), int(kv_heads))
+        Shorter lists are padded with sequence = -1 entries (the kernel returns immediately).
+
+        Grid balance: every 128-query item takes the same time and ATTN_SLOTS = 1024 blocks are resident at once, so the
+        1152 items of the benchmark batch run as one full round plus a round that is 1/8 full.  The last third of every
+        sequence's query blocks is therefore issued as HALF items (mode 1: 64 query rows, the key range split between the
+        wave pairs of the block): they take ~0.6 of a full item, sit at the end of every XCD list and fill the tail at a
+        finer grain (measured: -1 % on the whole forward; the kernel is bound by its softmax VALU work, not by the tail).
+        Which blocks are halved depends only on the sequence's own length, never on the rest of the batch, so a clip's
+        result does not depend on what it is packed with.
+        `split`: None = that rule, False = never, True = every item (tests)."""
+        if split is None and os.environ.get("TTV_ATTN_SPLIT") in ("0", "1"):      # diagnostics: A/B timing of the table kinds
+            split = os.environ["TTV_ATTN_SPLIT"] == "1"
+        key = (int(q_heads), int(kv_heads), split)
         t = self._attn.get(key)
         if t is None:
             rep = q_heads // kv_heads
-            units = []
+            units_full, units_half = [], []
             for b in range(len(self.grids)):
                 s = self.cu_seqlens[b + 1] - self.cu_seqlens[b]
+                nq = -(-s // QBLOCK)
+                first_half = 0 if split else (nq if split is False else nq - nq // 3)
                 for kvh in range(kv_heads):
-                    units.append([(b, q0, kvh * rep + r, 0) for q0 in range(0, s, QBLOCK) for r in range(rep)])
-            lists = [[] for _ in range(8)]
-            for u in sorted(units, key=len, reverse=True):
-                min(lists, key=len).extend(u)
+                    heads = [kvh * rep + r for r in range(rep)]
+                    units_full.append([(b, qb * QBLOCK, hd, 0) for qb in range(first_half) for hd in heads])
+                    units_half.append([(b, q0, hd, 1) for qb in range(first_half, nq) for hd in heads
+                                       for q0 in (qb * QBLOCK, qb * QBLOCK + 64) if q0 < s])
+            # a (sequence, kv-head) unit keeps one XCD list for its full and its half items
+            order = sorted(range(len(units_full)), key=lambda i: len(units_full[i]) + len(units_half[i]) / 2, reverse=True)
+            lists, weight, halves = [[] for _ in range(8)], [0.0] * 8, [[] for _ in range(8)]
+            for i in order:
+                x = min(range(8), key=lambda j: weight[j])
+                lists[x].extend(units_full[i])
+                halves[x].extend(units_half[i])
+                weight[x] += len(units_full[i]) + len(units_half[i]) / 2
+            for x in range(8):
+                lists[x].extend(halves[x])
             depth = max(len(l) for l in lists)
             table = np.full((depth, 8, 4), -1, dtype=np.int32)
             for x, l in enumerate(lists):
