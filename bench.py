@@ -9,9 +9,16 @@ resident in HBM before the timed region.  N > 1: one process per GPU (launched b
 tokenises its own 32 clips, no data-path collective (clips are independent - SURVEY.md 8e), scaling = weak;
 the timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
 
+Two independent batches are kept in flight per GPU by default (--in-flight 2, titok_video_amd/pipeline.py: one HIP stream each;
+inference batches do not depend on each other).  Every step is still one full TiTok.forward over 32 clips and exactly K of them
+are timed; ms_per_step is the elapsed time / K.  `one_batch_at_a_time` reports the same model with a single chain of launches
+(5 untimed-for-the-headline steps after the timed region), and --in-flight 1 times that mode as the headline instead.
+
 Extra objects on the JSON line:
   roofline     : the dominant kernel, timed live with HIP events recorded inside the C library on the
                  stream the kernel is launched on, during the timed steps; achieved = algorithmic FLOPs / launch / time.
+                 With two chains in flight a launch shares the CUs with the other chain's kernels, so its bracketed duration
+                 is longer than alone (`concurrent_chains`); `isolated` = the same launches with nothing else on the part.
   cpu_baseline : the CPU oracle (a port of the reference algorithm, verified against the reference's own code) timed
                  on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
   parity       : token-index agreement of the GPU path with that oracle on the sample.
@@ -32,6 +39,7 @@ if ROOT not in sys.path:
 
 from titok_video_amd import _lib  # noqa: E402
 from titok_video_amd.model.titok import TiTok  # noqa: E402
+from titok_video_amd.pipeline import ForwardPipeline  # noqa: E402
 from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips  # noqa: E402
 
 LEVELS = [7, 5, 5, 5, 5]
@@ -96,6 +104,9 @@ def main():
     ap.add_argument("--kernel", default="attention", choices=["attention", "gemm_qkv", "gemm_geglu"],
                     help="kernel class whose launches are timed for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent batches in flight per GPU (titok_video_amd.pipeline.ForwardPipeline: one HIP stream each); "
+                         "1 = one batch at a time")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,20 +142,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # A step = TiTok.forward (encode + quantise + decode) of one batch of BATCH clips.  Batches are independent (inference /
+    # evaluation: SURVEY.md 8e), so --in-flight of them are kept in flight on separate HIP streams: each is still a chain of 27
+    # dependent launches over 32 clips, the hardware fills one chain's partly empty rounds and launch gaps with the other's blocks.
+    pipe = ForwardPipeline(model, depth=args.in_flight) if args.in_flight > 1 else None
+
+    def step():
+        if pipe is not None:
+            pipe.submit(clips, counts)       # outputs are dropped here; a consumer would call pipe.result(ticket)
+        else:
+            model(clips, counts)
+
     with torch.no_grad():
         for _ in range(args.warmup):
-            model(clips, counts)
+            step()
         lib = _lib.lib()
         launches_per_step = 8     # 4 layers x 2 towers
         barrier()
         _lib.check(lib.ttv_prof_begin(_lib.KERNEL_CLASSES[args.kernel], launches_per_step * args.steps + 8), "prof_begin")
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            recon, out = model(clips, counts)
-        barrier()
+            step()
+        barrier()                            # torch.cuda.synchronize covers every stream of the device
         elapsed = time.perf_counter() - t0
         tot_ms, cnt = C.c_double(0), C.c_int(0)
         _lib.check(lib.ttv_prof_end(C.byref(tot_ms), C.byref(cnt)), "prof_end")
+        # a few steps one batch at a time, outside the timed region: the same kernels without a neighbour on the part
+        seq_steps = 5
+        iso_ms, iso_cnt, seq_elapsed = C.c_double(0), C.c_int(0), 0.0
+        if pipe is not None and rank == 0:
+            _lib.check(lib.ttv_prof_begin(_lib.KERNEL_CLASSES[args.kernel], launches_per_step * seq_steps + 8), "prof_begin")
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(seq_steps):
+                model(clips, counts)
+            torch.cuda.synchronize(device)
+            seq_elapsed = time.perf_counter() - t1
+            _lib.check(lib.ttv_prof_end(C.byref(iso_ms), C.byref(iso_cnt)), "prof_end")
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
@@ -172,12 +206,22 @@ def main():
             "config": {"workload": "configs/tiny.yaml (tiny enc+dec, FSQ [7,5,5,5,5]) bf16, batch 32 x 16x128x128 clips per GPU, "
                                    "K=128 latent tokens, TiTok.forward encode+decode", "clips_per_gpu": BATCH,
                        "tokens_per_clip": S, "parallelism": f"dp{world} (clips sharded, no collective)",
+                       "batches_in_flight": args.in_flight,
                        "algorithmic_gflop_per_clip": flops_clip / 1e9,
                        "whole_path_mfma_frac": value / world * flops_clip / (PEAK_BF16_TFLOPS * 1e12)},
             "roofline": {"kernel": args.kernel, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": kern_ms, "launches_timed": cnt.value, "flops_per_launch": kflops},
         }
+        if pipe is not None and iso_cnt.value > 0:
+            iso = iso_ms.value / iso_cnt.value
+            # with two chains in flight a launch shares the part with the other chain's kernels, so its bracketed duration is
+            # longer than the same launch alone; both are reported
+            line["roofline"]["concurrent_chains"] = args.in_flight
+            line["roofline"]["isolated"] = {"avg_launch_ms": iso, "achieved": kflops / (iso * 1e-3) / 1e12,
+                                            "frac": kflops / (iso * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "launches_timed": iso_cnt.value}
+            line["one_batch_at_a_time"] = {"value": BATCH * seq_steps / seq_elapsed, "ms_per_step": 1e3 * seq_elapsed / seq_steps,
+                                           "steps": seq_steps, "n_gpus": 1}
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(sd)
             line["cpu_baseline"] = base

@@ -289,3 +289,26 @@ def test_ragged_dynamic_batches_fp32_match_oracle():
             assert float((r.cpu() - rr).abs().max()) < 5e-3
         n += len(counts)
     assert n == 7
+
+
+def test_forward_pipeline_matches_sequential_calls():
+    """Two batches in flight on two streams (titok_video_amd.pipeline): bit-identical to one batch at a time, in order."""
+    from titok_video_amd.pipeline import ForwardPipeline
+    model = build(torch.bfloat16)
+    batches = []
+    for i, (shapes, counts) in enumerate([([(4, 16, 16), (8, 32, 48)], [3, 7]), ([(16, 64, 64)], [32]),
+                                          ([(4, 8, 24), (4, 16, 16), (8, 32, 32)], [1, 2, 9]), ([(8, 32, 48)], [5])]):
+        batches.append((synthetic_clips(shapes, seed=50 + i, dtype=torch.bfloat16, device=DEV), counts))
+    with torch.no_grad():
+        ref = [model(c, k) for c, k in batches]
+    torch.cuda.synchronize()
+    pipe = ForwardPipeline(model, depth=2)
+    tickets = [pipe.submit(c, k) for c, k in batches]
+    outs = [pipe.result(t) for t in tickets]
+    torch.cuda.synchronize()
+    for (r0, o0), (r1, o1) in zip(ref, outs):
+        assert torch.equal(o0["indices"], o1["indices"])
+        for a, b in zip(r0, r1):
+            assert torch.equal(a, b)
+    # the two streams really use separate scratch buffers
+    assert len({k[2] for k in model.encoder._ws}) >= 2

@@ -113,7 +113,10 @@ class _Tower(nn.Module):
         need = _lib.lib().ttv_tower_workspace_bytes(C.byref(dims), C.byref(plan.batch_for(self.heads[0], self.heads[1])))
         if need < 0:
             _lib.check(1, "ttv_tower_workspace_bytes")
-        key = (str(device), dims.dtype)
+        # one scratch buffer per (device, dtype, STREAM): forwards issued on different streams may run concurrently
+        # (titok_video_amd.pipeline.ForwardPipeline) and must not share it
+        stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        key = (str(device), dims.dtype, stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(int(need), dtype=torch.uint8, device=device)

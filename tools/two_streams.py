@@ -35,3 +35,20 @@ def bench(fn, n=50):
 t1 = bench(run_single); print(f"single stream : {t1*1e3:.3f} ms  {B/t1:8.0f} clips/s")
 for k in (2, 4):
     t = bench(make_split(k)); print(f"{k} streams     : {t*1e3:.3f} ms  {B/t:8.0f} clips/s")
+
+# ---- two FULL batches in flight (consecutive steps on two streams, one model instance per stream: the workspace is per model)
+m2 = TiTok(cfg); m2.load_state_dict(seeded_titok_state(0)); m2 = m2.to("cuda:0", torch.bfloat16).eval()
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+def run_pair():
+    with torch.cuda.stream(sa):
+        a = m(clips, counts)
+    with torch.cuda.stream(sb):
+        b = m2(clips, counts)
+    return a, b
+with torch.no_grad():
+    for _ in range(10): run_pair()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 50
+    for _ in range(n): run_pair()
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / n
+print(f"2 full batches in flight: {t*1e3:.3f} ms per pair  {2*B/t:8.0f} clips/s")
