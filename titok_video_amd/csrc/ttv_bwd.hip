@@ -1075,34 +1075,6 @@ __global__ __launch_bounds__(256) void k_attn_bwd_f32(const float* __restrict__ 
 // is stored at chunk position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 fragment read touches then cover all 64
 // banks once (unswizzled they fall on two 4-bank groups, 8-way), and the transposed reads drop from 4-way to 2-way. ----
 #define TSW(r_) (((r_) >> 1) & 7)
-__device__ __forceinline__ void stage_tile64(uint4* dst, const bf16_t* src, int ld, int row0, int row_end, int tid) {
-  // 64 rows x 8 chunks, 2 chunks per thread; rows past row_end are zero-filled
-  const uint4 zero4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (tid >> 3) + 32 * i, c = tid & 7;
-    dst[r * 8 + (c ^ TSW(r))] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
-  }
-}
-// The same staging split in two so that the global loads of the NEXT tile are in flight while the current one is used
-struct TileRegs { uint4 v[2]; };
-__device__ __forceinline__ TileRegs load_tile64(const bf16_t* src, int ld, int row0, int row_end, int tid) {
-  TileRegs t;
-  const uint4 zero4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (tid >> 3) + 32 * i, c = tid & 7;
-    t.v[i] = (row0 + r < row_end) ? *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8) : zero4;
-  }
-  return t;
-}
-__device__ __forceinline__ void store_tile64(uint4* dst, const TileRegs& t, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (tid >> 3) + 32 * i;
-    dst[r * 8 + ((tid & 7) ^ TSW(r))] = t.v[i];
-  }
-}
 // fragment with 8 consecutive COLUMNS of one row (K-contiguous operand): rows r0+l15, columns kc*8.. (b128)
 __device__ __forceinline__ bf16x8 frag_row(const uint4* tile, int row, int chunk) { return __builtin_bit_cast(bf16x8, tile[row * 8 + (chunk ^ TSW(row))]); }
 // fragment with 8 consecutive ROWS (row0 + 8*kq + 0..7) of one column col0 + l15: two transposed reads
