@@ -63,6 +63,15 @@ def _versions(params) -> tuple:
 class _Tower(nn.Module):
     kind = _lib.TTV_ENCODER
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .bfloat16() may replace parameter objects: drop the cached parameter list and gradient layout
+        self.__dict__.pop("_param_list_cache", None)
+        self.__dict__.pop("_grad_layout_cache", None)
+        out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_param_list_cache", None)
+        self.__dict__.pop("_grad_layout_cache", None)
+        return out
+
     def _setup(self, model_size, patch_size, pix_channels, token_size):
         self.model_size = model_size
         self.patch = tuple(int(p) for p in patch_size)
@@ -95,7 +104,7 @@ class _Tower(nn.Module):
         return cache[key]
 
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
-        params = list(self.parameters())
+        params = self._param_list()
         key = (dtype, str(device), _versions(params))
         if self._pack is None or self._pack_key != key:
             self._pack = _WeightPack(self, dtype, device)
@@ -130,81 +139,88 @@ class _Tower(nn.Module):
     def _wants_grad(self, *inputs) -> bool:
         if not torch.is_grad_enabled():
             return False
-        return any(p.requires_grad for p in self.parameters()) or any(getattr(t, "requires_grad", False) for t in inputs)
+        return any(p.requires_grad for p in self._param_list()) or any(getattr(t, "requires_grad", False) for t in inputs)
+
+    def _param_list(self):
+        """Parameters in registration order, cached (module.parameters() walks the module tree on every call)."""
+        pl = self.__dict__.get("_param_list_cache")
+        if pl is None:
+            pl = list(self.parameters())
+            self.__dict__["_param_list_cache"] = pl
+        return pl
+
+    def _grad_layout(self):
+        """(parameters, packed shapes, sizes, offsets, total) of the flat fp32 gradient buffer, in the order of the C struct; cached."""
+        lay = self.__dict__.get("_grad_layout_cache")
+        if lay is None:
+            ml = self.model_layers
+            named = []   # (parameter, packed shape)
+            named.append((self.proj_in.weight, tuple(self.proj_in.weight.shape)))
+            named.append((self.proj_in.bias, tuple(self.proj_in.bias.shape)))
+            named.append((self.mask_token, (1,)))
+            for m in (self.ln_pre_t, self.ln_pre_p, self.ln_post):
+                named.append((m.weight, (self.width,)))
+            named.append((self.proj_out.weight, tuple(self.proj_out.weight.shape)))
+            named.append((self.proj_out.bias, tuple(self.proj_out.bias.shape)))
+            for i in range(self.num_layers):
+                a, f = ml.attn_layer[i], ml.ffd_layer[i]
+                for prm in (a.pre_ln.weight, a.to_qkv.weight, a.out_proj.weight, f.norm.weight, f.w12.weight, f.w3.weight):
+                    named.append((prm, tuple(prm.shape)))
+                if i > 0:
+                    named.append((ml.attn_post_ln[i - 1].weight, (self.width,)))
+                    named.append((ml.ffd_post_ln[i - 1].weight, (self.width,)))
+            sizes = [int(math.prod(sh)) for _, sh in named]
+            offs, tot = [], 0
+            for n in sizes:
+                offs.append(tot)
+                tot += (n + 63) // 64 * 64
+            lay = ([p for p, _ in named], [sh for _, sh in named], sizes, offs, tot)
+            self.__dict__["_grad_layout_cache"] = lay
+        return lay
 
     def _grad_buffers(self, device):
-        """Zeroed fp32 gradient buffers in the PACKED weight layout + the C struct + per-parameter views."""
-        ml = self.model_layers
-        named = []   # (parameter, packed shape)
-        pd = self.pix_channels * math.prod(self.patch)
-        named.append((self.proj_in.weight, tuple(self.proj_in.weight.shape)))
-        named.append((self.proj_in.bias, tuple(self.proj_in.bias.shape)))
-        named.append((self.mask_token, (1,)))
-        for m in (self.ln_pre_t, self.ln_pre_p, self.ln_post):
-            named.append((m.weight, (self.width,)))
-        named.append((self.proj_out.weight, tuple(self.proj_out.weight.shape)))
-        named.append((self.proj_out.bias, tuple(self.proj_out.bias.shape)))
-        for i in range(self.num_layers):
-            a, f = ml.attn_layer[i], ml.ffd_layer[i]
-            for prm in (a.pre_ln.weight, a.to_qkv.weight, a.out_proj.weight, f.norm.weight, f.w12.weight, f.w3.weight):
-                named.append((prm, tuple(prm.shape)))
-            if i > 0:
-                named.append((ml.attn_post_ln[i - 1].weight, (self.width,)))
-                named.append((ml.ffd_post_ln[i - 1].weight, (self.width,)))
-        sizes = [int(math.prod(sh)) for _, sh in named]
-        offs, tot = [], 0
-        for n in sizes:
-            offs.append(tot)
-            tot += (n + 63) // 64 * 64
+        """Zeroed flat fp32 gradient buffer in the PACKED weight layout + the C struct pointing into it."""
+        params, shapes, sizes, offs, tot = self._grad_layout()
         flat = torch.zeros(tot, dtype=torch.float32, device=device)
-        views = [flat[o:o + n].view(sh) for o, n, (_, sh) in zip(offs, sizes, named)]
-        ptr = [v.data_ptr() for v in views]
+        base = flat.data_ptr()
+        ptr = [base + 4 * o for o in offs]
         lay = (_lib.LayerGrads * self.num_layers)()
         k = 8
         for i in range(self.num_layers):
-            fields = dict(pre_ln=ptr[k], to_qkv=ptr[k + 1], out_proj=ptr[k + 2], ffd_norm=ptr[k + 3], w12=ptr[k + 4], w3=ptr[k + 5])
+            L = lay[i]
+            L.pre_ln, L.to_qkv, L.out_proj, L.ffd_norm, L.w12, L.w3 = ptr[k:k + 6]
             k += 6
             if i > 0:
-                fields.update(attn_post_ln=ptr[k], ffd_post_ln=ptr[k + 1])
+                L.attn_post_ln, L.ffd_post_ln = ptr[k], ptr[k + 1]
                 k += 2
-            lay[i] = _lib.LayerGrads(**fields)
         st = _lib.TowerGrads(proj_in_w=ptr[0], proj_in_b=ptr[1], mask_token=ptr[2], ln_pre_t=ptr[3], ln_pre_p=ptr[4], ln_post=ptr[5],
                              proj_out_w=ptr[6], proj_out_b=ptr[7], layers=lay)
-        return flat, views, [p for p, _ in named], st, lay
+        return flat, st, lay
 
-    def _unpack_grads(self, params, views):
-        """Packed-layout fp32 gradients -> gradients in the reference parameter layout/dtype, keyed by parameter id."""
-        perm = self._patch_perm_on(views[0].device)
+    def _finish_grads(self, flat: torch.Tensor):
+        """Flat packed fp32 gradients -> {id(parameter): gradient in the reference layout and the parameter's dtype}: one cast of
+        the whole buffer (instead of a tiny kernel per parameter), one slice per parameter, the patch-order permutation undone."""
+        params, shapes, sizes, offs, _tot = self._grad_layout()
+        dt = params[0].dtype
+        conv = flat if dt == torch.float32 else flat.to(dt)
+        perm = None
         out = {}
-        for p, g in zip(params, views):
-            if g.dtype != p.dtype:
-                raise AssertionError("convert the flat buffer first (see _convert_views)")
+        for p, sh, n, o in zip(params, shapes, sizes, offs):
+            g = conv[o:o + n].view(sh)
             if p is self.mask_token:
                 g = g.view(1, 1)
-            elif self.kind == _lib.TTV_ENCODER and p is self.proj_in.weight:
+            elif (self.kind == _lib.TTV_ENCODER and p is self.proj_in.weight) or \
+                 (self.kind == _lib.TTV_DECODER and (p is self.proj_out.weight or p is self.proj_out.bias)):
+                if perm is None:
+                    perm = self._patch_perm_on(flat.device)
                 r = torch.empty_like(g)
-                r[:, perm] = g
-                g = r
-            elif self.kind == _lib.TTV_DECODER and p is self.proj_out.weight:
-                r = torch.empty_like(g)
-                r[perm, :] = g
-                g = r
-            elif self.kind == _lib.TTV_DECODER and p is self.proj_out.bias:
-                r = torch.empty_like(g)
-                r[perm] = g
+                if p is self.proj_in.weight:
+                    r[:, perm] = g
+                else:
+                    r[perm] = g          # rows of proj_out.weight / entries of proj_out.bias
                 g = r
             out[id(p)] = g
         return out
-
-    @staticmethod
-    def _convert_views(flat: torch.Tensor, views, params):
-        """One cast of the whole flat fp32 gradient buffer to the parameter dtype (instead of one tiny kernel per parameter)."""
-        dt = params[0].dtype
-        if dt == torch.float32:
-            return views
-        conv = flat.to(dt)
-        base = flat.data_ptr()
-        return [conv[(v.data_ptr() - base) // 4: (v.data_ptr() - base) // 4 + v.numel()].view(v.shape) for v in views]
 
 
 class _WeightPack:
@@ -370,8 +386,7 @@ class TiTokEncoder(_Tower):
         if self._wants_grad(*videos):
             counts = host_ints(token_counts)
             pix = [tuple(v.shape[1:]) for v in videos] if grids is None else [tuple(int(x) for x in g) for g in host_ints(grids)]
-            params = list(self.parameters())
-            return _EncoderTrainFn.apply(self, counts, pix, len(videos), *videos, *params)
+            return _EncoderTrainFn.apply(self, counts, pix, len(videos), *videos, *self._param_list())
         return self.run(videos, token_counts, grids, None, want_z=True)["z"]
 
     def forward(self, videos, token_counts, grids=None):
@@ -400,7 +415,7 @@ class TiTokDecoder(_Tower):
         if self._wants_grad(tokens):
             counts = host_ints(token_counts)
             pix = [tuple(int(v) for v in g) for g in host_ints(grids)]
-            outs = _DecoderTrainFn.apply(self, counts, pix, tokens, *list(self.parameters()))
+            outs = _DecoderTrainFn.apply(self, counts, pix, tokens, *self._param_list())
             return list(outs)
         device, dtype = tokens.device, tokens.dtype
         code = _lib.dtype_code(dtype)
@@ -467,12 +482,12 @@ class _EncoderTrainFn(torch.autograd.Function):
         # every parameter frozen (the generator step through the discriminator, loss_module.py:144-151): inputs-only backward
         frozen = dclips is not None and not any(p.requires_grad for p in ctx.params)
         if not frozen:
-            flat, views, params, gstruct, _lay = tower._grad_buffers(device)
+            flat, gstruct, _lay = tower._grad_buffers(device)
         rc = lib.ttv_encoder_backward(C.byref(ctx.dims), C.byref(ctx.pack.struct), C.byref(ctx.pack.transposed()), C.byref(ctx.batch),
                                       dz.contiguous().float().data_ptr(), ctx.tape.data_ptr(), None if frozen else C.byref(gstruct),
                                       _lib.ptr_array(dclips) if dclips else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_encoder_backward")
-        by_id = {} if frozen else tower._unpack_grads(params, tower._convert_views(flat, views, params))
+        by_id = {} if frozen else tower._finish_grads(flat)
         clip_grads = [dclips[i] if (dclips and ctx.clip_grad[i]) else None for i in range(ctx.n_clips)]
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None
@@ -503,7 +518,7 @@ class _DecoderTrainFn(torch.autograd.Function):
     def backward(ctx, *dclips):
         tower, device = ctx.tower, ctx.tokens.device
         lib = _lib.lib()
-        flat, views, params, gstruct, _lay = tower._grad_buffers(device)
+        flat, gstruct, _lay = tower._grad_buffers(device)
         ws = torch.empty(int(lib.ttv_tower_bwd_workspace_bytes(C.byref(ctx.dims), C.byref(ctx.batch))), dtype=torch.uint8, device=device)
         shapes = [(tower.out_channels, t, h, w) for (t, h, w) in ctx.plan.pixel_grids]
         dcl = [(g if g is not None else torch.zeros(sh, dtype=ctx.tokens.dtype, device=device)).to(ctx.tokens.dtype).contiguous()
@@ -513,7 +528,7 @@ class _DecoderTrainFn(torch.autograd.Function):
                                       ctx.tokens.data_ptr(), _lib.ptr_array(dcl), ctx.tape.data_ptr(), C.byref(gstruct),
                                       dcodes.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_decoder_backward")
-        by_id = tower._unpack_grads(params, tower._convert_views(flat, views, params))
+        by_id = tower._finish_grads(flat)
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None
         return (None, None, None, dcodes.to(ctx.tokens.dtype) if ctx.tokens_grad else None, *param_grads)
