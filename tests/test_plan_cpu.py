@@ -49,17 +49,19 @@ def test_plan_tables_match_oracle_metadata():
         assert plan.batch_for(hq, hkv).n_qblocks == len(plan.attention_table(hq, hkv))
 
 
-def test_attention_table_halves_the_last_third_of_each_sequence():
-    """Benchmark batch: 32 clips x 9 query blocks x 4 heads = 1152 items -> blocks 6..8 of every sequence become half items:
-    768 full + 768 half.  The choice depends on the sequence only."""
-    plan = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu")
+def test_attention_table_half_items_for_small_grids_only():
+    """Fewer items than resident slots (1024): blocks 6..8 of every 9-block sequence become half items, chosen per sequence;
+    the benchmark batch (1152 items) keeps full items."""
+    plan = BatchPlan([(16, 128, 128)] * 8, [128] * 8, (4, 8, 8), "cpu")
     tab = plan.attention_table(4, 2)
     real = tab[tab[:, 0] >= 0]
-    assert int((real[:, 3] == 0).sum()) == 768 and int((real[:, 3] == 1).sum()) == 768
+    assert int((real[:, 3] == 0).sum()) == 8 * 6 * 4 and int((real[:, 3] == 1).sum()) == 8 * 3 * 4 * 2
     one = BatchPlan([(16, 128, 128)], [128], (4, 8, 8), "cpu").attention_table(4, 2)
     one = one[one[:, 0] >= 0]
     mine = real[real[:, 0] == 7][:, 1:]
     assert sorted(map(tuple, mine.tolist())) == sorted(map(tuple, one[:, 1:].tolist()))   # same items alone and in the batch
+    big = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu").attention_table(4, 2)
+    assert int((big[:, 3] == 1).sum()) == 0 and int((big[:, 0] >= 0).sum()) == 1152
 
 
 def test_plan_rope_table_is_reference_bits():

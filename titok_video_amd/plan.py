@@ -157,13 +157,14 @@ class BatchPlan:
         are distributed over 8 lists (greedy by block count) and the lists are interleaved: entry i goes to list i % 8.
         Shorter lists are padded with sequence = -1 entries (the kernel returns immediately).
 
-        Grid balance: every 128-query item takes the same time and ATTN_SLOTS = 1024 blocks are resident at once, so the
-        1152 items of the benchmark batch run as one full round plus a round that is 1/8 full.  The last third of every
-        sequence's query blocks is therefore issued as HALF items (mode 1: 64 query rows, the key range split between the
-        wave pairs of the block): they take ~0.6 of a full item, sit at the end of every XCD list and fill the tail at a
-        finer grain (measured: -1 % on the whole forward; the kernel is bound by its softmax VALU work, not by the tail).
-        Which blocks are halved depends only on the sequence's own length, never on the rest of the batch, so a clip's
-        result does not depend on what it is packed with.
+        Half items (mode 1: 64 query rows, the key range split between the wave pairs of the block and merged in LDS) cost
+        ~0.6 of a full item for half the work.  They pay when the grid alone cannot fill the part: with fewer items than the
+        ATTN_SLOTS = 1024 blocks that are resident at once (batches below ~28 benchmark-size clips, e.g. the reference's
+        6144-token training batches) the last third of every sequence's query blocks is issued as half items and the launch
+        gets shorter (5 clips: 33 -> 27 us).  Larger grids keep full items: with a second batch in flight (pipeline.py) the
+        tail of one launch is filled by the other chain and the extra work of half items only costs (-3 % measured), alone
+        they are worth +1 %.  Within either regime the choice depends only on the sequence's own length, so a clip's bf16
+        result does not depend on what it is packed with (the fp32 kernel computes the same way in both modes).
         `split`: None = that rule, False = never, True = every item (tests)."""
         if split is None and os.environ.get("TTV_ATTN_SPLIT") in ("0", "1"):      # diagnostics: A/B timing of the table kinds
             split = os.environ["TTV_ATTN_SPLIT"] == "1"
@@ -171,11 +172,13 @@ class BatchPlan:
         t = self._attn.get(key)
         if t is None:
             rep = q_heads // kv_heads
+            n_items = sum(-(-(self.cu_seqlens[b + 1] - self.cu_seqlens[b]) // QBLOCK) for b in range(len(self.grids))) * q_heads
+            small_grid = n_items < ATTN_SLOTS
             units_full, units_half = [], []
             for b in range(len(self.grids)):
                 s = self.cu_seqlens[b + 1] - self.cu_seqlens[b]
                 nq = -(-s // QBLOCK)
-                first_half = 0 if split else (nq if split is False else nq - nq // 3)
+                first_half = 0 if split else (nq if (split is False or not small_grid) else nq - nq // 3)
                 for kvh in range(kv_heads):
                     heads = [kvh * rep + r for r in range(rep)]
                     units_full.append([(b, qb * QBLOCK, hd, 0) for qb in range(first_half) for hd in heads])
