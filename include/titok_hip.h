@@ -131,9 +131,14 @@ int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, 
  * full item, used by the host to fill the tail of the grid at a finer grain.  The host orders the table so that
  * entries i, i+8, i+16, ... (one XCD under round-robin dispatch) share a (sequence, kv-head): its K/V are then fetched into
  * one L2 only; half items come last.
- * If gate_mul == 0 the raw attention output is written. */
+ * flags: bit 0 (TTV_ATTN_GATE) multiply by sigmoid(gate), else the raw attention output is written; bit 1 (TTV_ATTN_PAIRED,
+ * bf16 only) the table is PAIRED: with the flat table read as rows of 8 list slots (entry i belongs to list i % 8), entries
+ * 2j and 2j+1 of a list describe the same (sequence, query rows, mode) for two q-heads of one kv-head; one 8-wave block then
+ * computes both and stages every K / V tile once for the two heads. */
+#define TTV_ATTN_GATE 1
+#define TTV_ATTN_PAIRED 2
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
-                  int n_qblocks, int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream);
+                  int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 
 /* patch_rearrange (model/base/utils.py:26-34) for up to TTV_MAX_CLIPS_PER_LAUNCH clips per call.
  * clips: HOST array of device pointers [n_clips] to [C,T,H,W] tensors; clip_desc: DEVICE int32 [n_clips,8] =
@@ -213,6 +218,8 @@ typedef struct ttv_batch {
   const int32_t* blocks64;     /* [n_blocks64,2] (sequence, first row) of every 64-row block (attention backward) */
   const int32_t* row_seq;      /* [L] sequence id of every packed row */
   int32_t n_blocks64;
+  int32_t qblocks_paired;      /* 1: entries 2j, 2j+1 of every XCD list of `qblocks` are the same query rows of two q-heads sharing
+                                  a kv-head (ttv_attention flag TTV_ATTN_PAIRED); 0: no such guarantee */
 } ttv_batch;
 
 /* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =

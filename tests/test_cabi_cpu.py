@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.TowerDims) == 15 * 4
     assert C.sizeof(_lib.LayerWeights) == 12 * 8   # 11 pointers + int32 mlp_pack_qkv_rows (padded)
     assert C.sizeof(_lib.TowerWeights) == 10 * 8
-    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 8   # + blocks64, row_seq, n_blocks64 (padded)
+    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 8   # + blocks64, row_seq, n_blocks64, qblocks_paired
     src = open(HEADER).read()
     for struct, cls in [("ttv_fsq_params", _lib.FsqParams), ("ttv_tower_dims", _lib.TowerDims),
                         ("ttv_layer_weights", _lib.LayerWeights), ("ttv_tower_weights", _lib.TowerWeights),

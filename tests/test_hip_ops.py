@@ -342,10 +342,13 @@ def test_layer_tail_fused(M, keel, back):
                                   ([(16, 128, 128)], [128]), ([(4, 8, 8), (4, 8, 8)], [0, 63])])
 @pytest.mark.parametrize("heads", [(4, 2), (12, 4)])
 @pytest.mark.parametrize("split", [False, True])
-def test_attention_varlen_gqa_gate(dt, case, heads, split):
+@pytest.mark.parametrize("paired", [0, 2])
+def test_attention_varlen_gqa_gate(dt, case, heads, split, paired):
     shapes, counts = case
     plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
     hq, hkv = heads
+    if paired and ((hq // hkv) % 2 or dt != "bf16"):
+        pytest.skip("paired tables need an even number of q-heads per kv-head and the bf16 kernel")
     d, gq = hq * 64, hkv * 64
     ld = 2 * d + 2 * gq
     g = torch.Generator().manual_seed(len(shapes) + hq)
@@ -358,7 +361,7 @@ def test_attention_varlen_gqa_gate(dt, case, heads, split):
         tab = plan.attention_table(hq, hkv, split)     # 128-query items / 64-query half items (key range split in-block)
         out.fill_(float("nan"))
         _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
-                                     tab.shape[0], hq, hkv, 64, gate, _lib.dtype_code(DT[dt]), S()), "attention")
+                                     tab.shape[0], hq, hkv, 64, gate | paired, _lib.dtype_code(DT[dt]), S()), "attention")
         f = qkvg.float()
         q, gt, k, v = f.split([d, d, gq, gq], dim=-1)
         ref = O.attention_varlen(q.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)),

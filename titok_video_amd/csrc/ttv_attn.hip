@@ -27,22 +27,44 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds_ptr));
 }
 
-template <bool GATE>
-__global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
-                                                      const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model,
-                                                      int gqa, int rep, float c_exp /* scale*log2(e) */, float* __restrict__ lse_out) {
+// NE = table entries per block.  NE == 2 ("paired" tables, plan.attention_table): a block of 8 waves takes entries 2j and 2j+1 of
+// its XCD list - the same query rows of the two q-heads that share a kv-head - so every K / V tile is staged ONCE for both heads
+// (half the tile traffic through L2 and LDS per score).  Waves 0-3 work on the first entry, 4-7 on the second, exactly as the
+// four waves of an NE == 1 block; only the staging is split eight ways.
+template <bool GATE, int NE>
+__global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
+                                                           const int* __restrict__ cu, const int* __restrict__ qblocks, int n_entries,
+                                                           int d_model, int gqa, int rep, float c_exp /* scale*log2(e) */,
+                                                           float* __restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) uint4 kl[2][KB * 8];
   __shared__ __attribute__((aligned(16))) uint4 vl[2][KB * 8];
+  __shared__ float xm_s[NE * 2 * 2 * 64];       // half items: (m, l) hand-over of the second wave pair of each entry
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave in the block (0 .. 4 NE - 1), scalar: staging share
+  const int ent = NE == 2 ? (w8 >> 2) : 0;       // which of the block's entries this wave works on
+  const int wave = w8 & 3;                       // wave within the entry
   const int r = lane & 31, h = lane >> 5;
-  // work table entry: (sequence, first query row, q-head); sequence < 0 = padding entry of the XCD-interleaved order
-  const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
+  // work table entry: (sequence, first query row, q-head, mode); sequence < 0 = padding entry of the XCD-interleaved order.
+  // Paired: entries (2j, 2j+1) of list x = blockIdx % 8 sit at flat rows (2j) * 8 + x and (2j + 1) * 8 + x.
+  int tix = blockIdx.x;
+  bool live = true;
+  if (NE == 2) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int ta = (2 * j) * 8 + x, tb = ta + 8;
+    const int sa = ta < n_entries ? qblocks[4 * ta] : -1, sb = tb < n_entries ? qblocks[4 * tb] : -1;
+    if (sa < 0 && sb < 0) return;
+    live = (ent ? sb : sa) >= 0;
+    // an odd list length leaves one entry without a partner: its second wave quad shadows it (same staging share and barriers)
+    // and stores nothing
+    tix = live ? (ent ? tb : ta) : (ent ? ta : tb);
+  }
+  const int seq = qblocks[4 * tix], q0 = qblocks[4 * tix + 1], head = qblocks[4 * tix + 2];
   // mode 1 = "half item": 64 query rows; waves 0,1 take the first half of the key range, waves 2,3 the second half (32-key
   // tiles, one per wave and step) and the two partial (O, m, l) states are merged through LDS at the end.  A half item takes
   // about 0.6 of the time of a full one; the host puts them at the end of the table where they fill the tail of the grid
   // (plan.attention_table).
-  const int mode = qblocks[4 * blockIdx.x + 3];
+  const int mode = qblocks[4 * tix + 3];
   if (seq < 0) return;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
   const int kvh = head / rep;
@@ -63,10 +85,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   // lane & 7 the 16-byte LDS chunk; the DMA writes lanes linearly, so the XOR swizzles are applied on the global side (the lane
   // fetches the chunk that belongs at its LDS position): K chunk c holds global chunk c ^ ((row >> 1) & 7), V chunk c holds
   // c ^ (((row >> 1) & 1) << 2).  Rows past the sequence end re-fetch its last row (masked in the scores).
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wave_s = __builtin_amdgcn_readfirstlane(w8);       // staging share: wave w8 of 4 NE
   const uint32_t kl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&kl[0][0];
   const uint32_t vl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&vl[0][0];
-  const int drow0 = (wave_s * 2) * 8 + (lane >> 3), drow1 = drow0 + 8;
+  constexpr int DPW = 2 / NE;                                   // DMA instructions per wave, tile and operand
+  const int drow0 = (wave_s * DPW) * 8 + (lane >> 3), drow1 = drow0 + 8;
   const int kc0 = ((lane & 7) ^ ((drow0 >> 1) & 7)) * 8, kc1 = ((lane & 7) ^ ((drow1 >> 1) & 7)) * 8;
   const int vc0 = ((lane & 7) ^ (((drow0 >> 1) & 1) << 2)) * 8, vc1 = ((lane & 7) ^ (((drow1 >> 1) & 1) << 2)) * 8;
 #define DMA16(voff_, base_, dst_)                                                                                \
@@ -78,15 +101,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   // tile rows 0..31 <- keys base0_ + row, rows 32..63 <- keys base1_ + (row - 32)   (waves 0,1 stage the first, 2,3 the second half)
 #define DMA2(base0_, base1_, buf_)                                                                               \
   do {                                                                                                           \
-    const int rb__ = wave_s < 2 ? (base0_) : (base1_) - 32;                                                      \
+    const int rb__ = wave_s < 2 * NE ? (base0_) : (base1_) - 32;                                                 \
     int g0__ = rb__ + drow0, g1__ = rb__ + drow1;                                                                \
     g0__ = g0__ < S ? g0__ : S - 1;                                                                              \
     g1__ = g1__ < S ? g1__ : S - 1;                                                                              \
-    const uint32_t dk__ = kl_lds + (buf_) * (KB * 128) + wave_s * 2048, dv__ = vl_lds + (buf_) * (KB * 128) + wave_s * 2048; \
+    const uint32_t dk__ = kl_lds + (buf_) * (KB * 128) + wave_s * (1024 * DPW);                                  \
+    const uint32_t dv__ = vl_lds + (buf_) * (KB * 128) + wave_s * (1024 * DPW);                                  \
     DMA16((uint32_t)(g0__ * ld + kc0) * 2u, kbase, dk__);                                                        \
-    DMA16((uint32_t)(g1__ * ld + kc1) * 2u, kbase, dk__ + 1024);                                                 \
+    if (DPW == 2) DMA16((uint32_t)(g1__ * ld + kc1) * 2u, kbase, dk__ + 1024);                                   \
     DMA16((uint32_t)(g0__ * ld + vc0) * 2u, vbase, dv__);                                                        \
-    DMA16((uint32_t)(g1__ * ld + vc1) * 2u, vbase, dv__ + 1024);                                                 \
+    if (DPW == 2) DMA16((uint32_t)(g1__ * ld + vc1) * 2u, vbase, dv__ + 1024);                                   \
   } while (0)
 
   f32x16 o_acc[2];
@@ -296,8 +320,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
     }
     __syncthreads();   // every wave is done with the tiles: they become the exchange buffer
     // merge the two key halves: pair 1 hands its state to pair 0 (same query rows, same lane layout) through the K / V tiles
-    f32x4* xo = reinterpret_cast<f32x4*>(&kl[0][0]);      // [qg][8][64 lanes] float4 = 16 KB
-    float* xm = reinterpret_cast<float*>(&vl[0][0]);      // [qg][m | l][64 lanes]
+    // O state: 16 KB per entry ([qg][8][64 lanes] float4) - entry 0 in the K tiles, entry 1 in the V tiles; (m, l) in xm_s
+    f32x4* xo = reinterpret_cast<f32x4*>(ent ? &vl[0][0] : &kl[0][0]);
+    float* xm = xm_s + ent * 256;                         // [qg][m | l][64 lanes]
     const int qg = wave & 1;
     if (kh == 1) {
 #pragma unroll
@@ -332,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bf16(const bf16_t* __restrict__
   // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = 1.0f / l_tot;
+  if (!live) return;
   if (lse_out && qrow < S && h == 0)   // natural-log LSE of the scaled scores (training tape): scale*max + ln(sum)
     lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run * (c_exp * 0.69314718055994530942f) + __logf(l_tot);
   if (qrow < S) {
@@ -434,8 +460,10 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
   }
 }
 
+// flags: bit 0 (TTV_ATTN_GATE) multiply by sigmoid(gate); bit 1 (TTV_ATTN_PAIRED) the table is paired (see k_attn_bf16, NE = 2)
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
-                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s, float* lse_out) {
+                   int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out) {
+  const int gate_mul = flags & 1, paired = (flags >> 1) & 1;
   if (n_qblocks == 0) return TTV_OK;
   TTV_CHECK_ARG(head_dim == 64, "attention: head_dim %d unsupported (the reference fixes 64, utils.py:8)", head_dim);
   TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention: q_heads %% kv_heads");
@@ -447,8 +475,16 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   TtvProfScope prof(TTV_KC_ATTENTION, s);
   if (dtype == TTV_BF16) {
     const float c_exp = scale * 1.44269504088896340736f;
-    if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
-    else hipLaunchKernelGGL((k_attn_bf16<false>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
+    if (paired) {
+      // rows of 8 list slots; a block takes two consecutive rows of one slot
+      const int rows = ttv_cdiv(n_qblocks, 8), pairs = ttv_cdiv(rows, 2);
+      dim3 g2(pairs * 8);
+      if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true, 2>), g2, dim3(512), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
+      else hipLaunchKernelGGL((k_attn_bf16<false, 2>), g2, dim3(512), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
+    } else {
+      if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true, 1>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
+      else hipLaunchKernelGGL((k_attn_bf16<false, 1>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
+    }
   } else if (dtype == TTV_F32) {
     const size_t smem = (QB * 64 + KB * 65 + KB * 64 + 4 * 64) * sizeof(float);
     if (gate_mul) {

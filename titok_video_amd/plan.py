@@ -209,7 +209,12 @@ class BatchPlan:
     def batch_for(self, q_heads: int, kv_heads: int) -> "_lib.Batch":
         """ttv_batch struct whose attention work table matches the tower's head counts."""
         t = self.attention_table(q_heads, kv_heads)
-        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), **self._base_fields)
+        # every (sequence, kv-head) unit contributes its entries in runs of `rep` q-heads per query block, full items first:
+        # with an even rep, entries 2j and 2j+1 of an XCD list are two q-heads of one kv-head on the same query rows
+        # (opt-in, TTV_ATTN_PAIRED=1: the 8-wave blocks halve the K/V tile traffic - +1.5 % with two batches in flight - but make
+        # the grid coarser: the launch alone is 10 % slower)
+        paired = 1 if (q_heads // kv_heads) % 2 == 0 and os.environ.get("TTV_ATTN_PAIRED", "0") == "1" else 0
+        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, **self._base_fields)
 
     # views used by tests that call single ops
     def table(self, i: int, n: int) -> torch.Tensor:
