@@ -322,7 +322,7 @@ int ttv_attention_backward(const void* qkvg, int ld, const void* o, int ldo, con
                            void* stream);
 /* ttv_attention with an extra fp32 [L,q_heads] log-sum-exp output (training forward). */
 int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
-                      int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, float* lse, void* stream);
+                      int q_heads, int kv_heads, int head_dim, int flags, int dtype, float* lse, void* stream);
 
 /* ---- codebook statistics (train_utils/codebook_logging.py:19-32) -------------------------------------- */
 /* counts[idx] += 1 for every index (int64 device histogram, atomics); usage/entropy are finished on the host. */

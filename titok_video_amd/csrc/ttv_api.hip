@@ -274,9 +274,9 @@ int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, 
 }
 
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
-                  int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, void* stream) {
+                  int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream) {
   TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention: null buffer");
-  return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, gate_mul, dtype, (hipStream_t)stream);
+  return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, flags, dtype, (hipStream_t)stream);
 }
 
 int ttv_patch_gather(const void* const* clips, const int32_t* clip_desc, int clip0, int n_clips, int patch_t, int patch_h, int patch_w,

@@ -394,9 +394,9 @@ int ttv_attention_backward(const void* qkvg, int ld, const void* o, int ldo, con
 }
 
 int ttv_attention_lse(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
-                      int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, float* lse, void* stream) {
+                      int q_heads, int kv_heads, int head_dim, int flags, int dtype, float* lse, void* stream) {
   TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention_lse: null buffer");
-  return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, gate_mul, dtype, (hipStream_t)stream, lse);
+  return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, flags, dtype, (hipStream_t)stream, lse);
 }
 
 }  // extern "C"
