@@ -11,6 +11,7 @@ from types import SimpleNamespace
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from titok_video_amd import plan as plan_mod  # noqa: E402
 from titok_video_amd.data import SyntheticClipStream, dynamic_batches  # noqa: E402
 from titok_video_amd.model.titok import TiTok  # noqa: E402
 from titok_video_amd.synthetic import seeded_titok_state  # noqa: E402
@@ -33,6 +34,7 @@ with torch.no_grad():
     for b in batches[:5]:
         model(b["video"], b["counts"])
     torch.cuda.synchronize()
+    plan_mod._plan_cache.clear()        # every timed batch builds its plan (a loader never repeats a batch shape)
     t0 = time.perf_counter()
     for b in batches:
         model(b["video"], b["counts"])
@@ -40,6 +42,21 @@ with torch.no_grad():
     dt = time.perf_counter() - t0
 out = {"ragged_inference": {"batches": len(batches), "clips": nclips, "packed_rows": rows, "clips_per_s": nclips / dt, "rows_per_s": rows / dt,
                             "ms_per_batch": 1e3 * dt / len(batches)}}
+
+# the same batches with several of them in flight (titok_video_amd.pipeline): small ragged batches under-fill the part even more
+from titok_video_amd.pipeline import ForwardPipeline  # noqa: E402
+for depth in (2, 3):
+    pipe = ForwardPipeline(model, depth=depth)
+    for b in batches[:5]:
+        pipe.submit(b["video"], b["counts"])
+    torch.cuda.synchronize()
+    plan_mod._plan_cache.clear()
+    t0 = time.perf_counter()
+    for b in batches:
+        pipe.submit(b["video"], b["counts"])
+    torch.cuda.synchronize()
+    dtp = time.perf_counter() - t0
+    out[f"ragged_inference_{depth}_in_flight"] = {"clips_per_s": nclips / dtp, "ms_per_batch": 1e3 * dtp / len(batches)}
 
 model = model.float()          # fp32 master weights, bf16 compute through the clips' dtype is not wired for mixed precision yet: train in bf16 params
 model = model.to(torch.bfloat16).train()
