@@ -39,6 +39,27 @@ def _rope_base_table(head_dim: int, nd: int, n_ids: int, theta: float = 10000.0)
     return fc.real.to(torch.float32).numpy(), fc.imag.to(torch.float32).numpy()
 
 
+_copy_streams = {}
+
+
+def _upload(host: np.ndarray, device) -> torch.Tensor:
+    """Host table -> device, complete on return, without waiting for compute.  A plain `.to(device)` from pageable memory is
+    ordered after everything queued on the current stream, i.e. it waits for the previous batch's forward, which serialises the
+    host with the GPU when every batch needs a new plan (ragged batches from a loader).  Here the copy goes through pinned
+    memory on a stream of its own and only that copy is waited for (~10 us), so the table can be used from any stream."""
+    t = torch.from_numpy(host)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return t.to(dev)
+    cs = _copy_streams.get(str(dev))
+    if cs is None:
+        cs = _copy_streams[str(dev)] = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(cs):
+        out = t.pin_memory().to(dev, non_blocking=True)
+    cs.synchronize()
+    return out
+
+
 @functools.lru_cache(maxsize=16)
 def _rope_base_device(head_dim: int, nd: int, n_ids: int, device: str):
     c, s_ = _rope_base_table(head_dim, nd, n_ids)
@@ -123,7 +144,7 @@ class BatchPlan:
         host = np.zeros(total, dtype=np.int32)
         for o, p in zip(offs, parts):
             host[o:o + p.size] = p
-        self.int_tables = torch.from_numpy(host).to(self.device, non_blocking=False)
+        self.int_tables = _upload(host, self.device)
         base = self.int_tables.data_ptr()
         if self.device.type == "cuda":
             # gather on the device from the (cached, device-resident) base table: no per-batch trigonometry, no big upload
@@ -202,7 +223,7 @@ class BatchPlan:
             # drop trailing all-padding rows only (interior padding keeps the i % 8 alignment)
             flat = table.reshape(-1, 4)
             last = int(np.max(np.nonzero(flat[:, 0] >= 0)[0])) + 1
-            t = torch.from_numpy(np.ascontiguousarray(flat[:last])).to(self.device)
+            t = _upload(np.ascontiguousarray(flat[:last]), self.device)
             self._attn[key] = t
         return t
 
