@@ -137,6 +137,7 @@ int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, 
  * computes both and stages every K / V tile once for the two heads. */
 #define TTV_ATTN_GATE 1
 #define TTV_ATTN_PAIRED 2
+#define TTV_ATTN_QSCALED 4   /* bf16: the q columns already carry the factor head_dim^-0.5 * log2(e) (see ttv_layer_weights.qkv_q_prescaled) */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 
@@ -182,6 +183,10 @@ typedef struct ttv_layer_weights {
    * layer-tail kernel; mlp_pack_qkv_rows = rows of the next layer's to_qkv packed into it (0 = none, e.g. last layer) */
   const void* mlp_pack;
   int32_t mlp_pack_qkv_rows;
+  /* 1: the q rows of to_qkv_pn (and of the next-layer image inside the previous layer's mlp_pack) are multiplied by
+   * head_dim^-0.5 * log2(e): the projection then emits the softmax exponent directly and the attention kernel runs with
+   * TTV_ATTN_QSCALED (one multiply-add less per score).  Inference towers only; `to_qkv` itself is never scaled. */
+  int32_t qkv_q_prescaled;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {

@@ -343,25 +343,31 @@ def test_layer_tail_fused(M, keel, back):
 @pytest.mark.parametrize("heads", [(4, 2), (12, 4)])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("paired", [0, 2])
-def test_attention_varlen_gqa_gate(dt, case, heads, split, paired):
+@pytest.mark.parametrize("qscaled", [0, 4])
+def test_attention_varlen_gqa_gate(dt, case, heads, split, paired, qscaled):
     shapes, counts = case
     plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
     hq, hkv = heads
     if paired and ((hq // hkv) % 2 or dt != "bf16"):
         pytest.skip("paired tables need an even number of q-heads per kv-head and the bf16 kernel")
+    if qscaled and dt != "bf16":
+        pytest.skip("pre-scaled q is a bf16 kernel option")
     d, gq = hq * 64, hkv * 64
     ld = 2 * d + 2 * gq
     g = torch.Generator().manual_seed(len(shapes) + hq)
     qkvg = torch.randn(plan.total_rows, ld, generator=g)
     qkvg[:, :d] *= 2.0            # sharper softmax
+    q_f32 = qkvg[:, :d].clone()
     qkvg = qkvg.to(DT[dt])
     out = torch.empty(plan.total_rows, d, dtype=DT[dt], device=DEV)
     xd = qkvg.to(DEV)
+    if qscaled:      # TTV_ATTN_QSCALED: q carries head_dim^-0.5 * log2(e), applied before the one rounding to bf16
+        xd[:, :d] = (q_f32 * (0.125 * 1.4426950408889634)).to(DT[dt]).to(DEV)
     for gate in (1, 0):
         tab = plan.attention_table(hq, hkv, split)     # 128-query items / 64-query half items (key range split in-block)
         out.fill_(float("nan"))
         _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
-                                     tab.shape[0], hq, hkv, 64, gate | paired, _lib.dtype_code(DT[dt]), S()), "attention")
+                                     tab.shape[0], hq, hkv, 64, gate | paired | qscaled, _lib.dtype_code(DT[dt]), S()), "attention")
         f = qkvg.float()
         q, gt, k, v = f.split([d, d, gq, gq], dim=-1)
         ref = O.attention_varlen(q.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)),

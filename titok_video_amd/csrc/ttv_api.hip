@@ -100,9 +100,11 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
       TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     }
+    // q arrives pre-scaled when the projection used the folded weight whose q rows carry scale * log2(e)
+    const bool q_scaled = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn && lw.qkv_q_prescaled;
     qkv_ready = false;
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
-                           TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0), dt, s));
+                           TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0), dt, s));
     // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h).
     // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
     // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs

@@ -31,7 +31,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 // its XCD list - the same query rows of the two q-heads that share a kv-head - so every K / V tile is staged ONCE for both heads
 // (half the tile traffic through L2 and LDS per score).  Waves 0-3 work on the first entry, 4-7 on the second, exactly as the
 // four waves of an NE == 1 block; only the staging is split eight ways.
-template <bool GATE, int NE>
+// PRE: the q columns arrive multiplied by scale * log2(e) (folded into the q rows of the projection weight by the host, one rounding,
+// ttv_layer_weights.qkv_q_prescaled): S is then already the exponent.  The running maximum is carried INSIDE the MFMA accumulator -
+// the score tiles start from -m instead of 0 - so a score needs no multiply-subtract before its exp2 (4 instead of 5 issue slots);
+// when a tile raises the maximum (rare after the first tiles) the tile's scores, the running state and the start vector are shifted.
+template <bool GATE, int NE, bool PRE>
 __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
                                                            const int* __restrict__ cu, const int* __restrict__ qblocks, int n_entries,
                                                            int d_model, int gqa, int rep, float c_exp /* scale*log2(e) */,
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 #pragma unroll
     for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  if (PRE) c_exp = 1.0f;     // the scores are exponents already
 
   // ---- lane-constant LDS byte offsets, hoisted out of the key loop (all per-tile variation is an immediate) ----
   // K fragment (A operand of S^T): key row t*32 + r, 16-byte chunk (2ks + h) ^ ((row>>1)&7); (row>>1)&7 == (r>>1)&7
@@ -140,6 +145,8 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 
   const int nkt = (S + KB - 1) / KB;
   if (mode == 0) {
+  f32x16 negm = zero16;            // PRE: start vector of the score accumulators = -m_run per lane (query)
+  if (PRE) m_run = 0.f;            // placeholder until the first tile sets the maximum
   DMA2(0, 32, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], ks ? s_acc[t] : zero16, 0, 0, 0);
+          s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], ks ? s_acc[t] : (PRE ? negm : zero16), 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -189,9 +196,35 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s_acc[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float psum = 0.f;
+    if (PRE) {
+      // the tile's scores are relative to the running maximum (they started from -m_run): a positive one raises it
+      if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0ull) {
+        const float d = kt == 0 ? mx - m_run : fmaxf(mx, 0.f);      // first tile: m_run is the placeholder 0
+        const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-d);   // nothing accumulated yet on the first tile
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s_acc[t][e] -= d;
+        m_run += d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[e] = -m_run;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          s_acc[t][e] = __builtin_amdgcn_exp2f(s_acc[t][e]);
+          psum += s_acc[t][e];
+        }
+    } else {
     const float m_new = fmaxf(m_run, mx);
     const float mc = m_new * c_exp;
-    float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -208,6 +241,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 #pragma unroll
         for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
       m_run = m_new;
+    }
     }
     l_run += psum;
     // P as bf16 B-operand fragments: k-step (t, sp) = registers 8sp..8sp+7 of score tile t
@@ -463,7 +497,8 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
 // flags: bit 0 (TTV_ATTN_GATE) multiply by sigmoid(gate); bit 1 (TTV_ATTN_PAIRED) the table is paired (see k_attn_bf16, NE = 2)
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
                    int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out) {
-  const int gate_mul = flags & 1, paired = (flags >> 1) & 1;
+  const int gate_mul = flags & 1, paired = (flags >> 1) & 1, prescaled = (flags >> 2) & 1;
+  TTV_CHECK_ARG(!prescaled || dtype == TTV_BF16, "attention: pre-scaled q is a bf16 path option");
   if (n_qblocks == 0) return TTV_OK;
   TTV_CHECK_ARG(head_dim == 64, "attention: head_dim %d unsupported (the reference fixes 64, utils.py:8)", head_dim);
   TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention: q_heads %% kv_heads");
@@ -475,16 +510,24 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   TtvProfScope prof(TTV_KC_ATTENTION, s);
   if (dtype == TTV_BF16) {
     const float c_exp = scale * 1.44269504088896340736f;
+#define ATTN_LAUNCH(G_, NE_, P_, grid_, threads_)                                                                                   \
+  hipLaunchKernelGGL((k_attn_bf16<G_, NE_, P_>), grid_, dim3(threads_), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, \
+                     qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out)
+#define ATTN_PICK(NE_, grid_, threads_)                                                  \
+  do {                                                                                   \
+    if (gate_mul) { if (prescaled) ATTN_LAUNCH(true, NE_, true, grid_, threads_); else ATTN_LAUNCH(true, NE_, false, grid_, threads_); }   \
+    else { if (prescaled) ATTN_LAUNCH(false, NE_, true, grid_, threads_); else ATTN_LAUNCH(false, NE_, false, grid_, threads_); }          \
+  } while (0)
     if (paired) {
       // rows of 8 list slots; a block takes two consecutive rows of one slot
       const int rows = ttv_cdiv(n_qblocks, 8), pairs = ttv_cdiv(rows, 2);
       dim3 g2(pairs * 8);
-      if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true, 2>), g2, dim3(512), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
-      else hipLaunchKernelGGL((k_attn_bf16<false, 2>), g2, dim3(512), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
+      ATTN_PICK(2, g2, 512);
     } else {
-      if (gate_mul) hipLaunchKernelGGL((k_attn_bf16<true, 1>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
-      else hipLaunchKernelGGL((k_attn_bf16<false, 1>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out);
+      ATTN_PICK(1, grid, 256);
     }
+#undef ATTN_PICK
+#undef ATTN_LAUNCH
   } else if (dtype == TTV_F32) {
     const size_t smem = (QB * 64 + KB * 65 + KB * 64 + 4 * 64) * sizeof(float);
     if (gate_mul) {

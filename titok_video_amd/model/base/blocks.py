@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -245,18 +246,24 @@ class _WeightPack:
 
         fold = dtype == torch.bfloat16 and tower.width == 256
 
-        def folded(w, g):
+        # q rows of the folded QKV weight carry head_dim^-0.5 * log2(e): the projection then emits the softmax exponent and the
+        # attention kernel saves a multiply-add per score (TTV_ATTN_QSCALED).  Applied in fp32 before the one rounding to bf16.
+        q_scale = 0.125 * 1.4426950408889634 if (fold and os.environ.get("TTV_ATTN_QSCALE", "1") != "0") else None
+        self.q_prescaled = 1 if q_scale is not None else 0
+
+        def folded_tensor(w, g, q_rows=0):
+            t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
+            if q_rows and q_scale is not None:
+                t[:q_rows] *= q_scale
+            return t.to(dtype).contiguous()
+
+        def folded(w, g, q_rows=0):
             """w * gain[None, :] in fp32, then the compute dtype: lets the K=256 GEMM kernel absorb the pre-norm."""
             if not fold:
                 return None
-            t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
-            t = t.to(dtype).contiguous()
+            t = folded_tensor(w, g, q_rows)
             keep.append(t)
             return t.data_ptr()
-
-        def folded_tensor(w, g):
-            t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
-            return t.to(dtype).contiguous()
 
         def mlp_packed(w12, g, w3, wo, next_attn):
             """Panel images of the fused layer-tail kernel (csrc/ttv_mlp.hip), built on the device by ttv_mlp_pack from
@@ -269,7 +276,7 @@ class _WeightPack:
             woc = wo.detach().to(device=device, dtype=dtype).contiguous()
             wq, rows = None, 0
             if next_attn is not None and next_attn.to_qkv.weight.shape[0] % 64 == 0:
-                wq = folded_tensor(next_attn.to_qkv.weight, next_attn.pre_ln.weight)
+                wq = folded_tensor(next_attn.to_qkv.weight, next_attn.pre_ln.weight, q_rows=tower.width)
                 rows = int(wq.shape[0])
             inner = int(w3.shape[1])
             out = torch.empty(_lib.lib().ttv_mlp_pack_bytes(inner, rows), dtype=torch.uint8, device=device)
@@ -299,8 +306,8 @@ class _WeightPack:
                 ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
                 ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
-                to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight), w12_pn=folded(f.w12.weight, f.norm.weight),
-                mlp_pack=pack_ptr, mlp_pack_qkv_rows=pack_rows)
+                to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight, q_rows=tower.width), w12_pn=folded(f.w12.weight, f.norm.weight),
+                mlp_pack=pack_ptr, mlp_pack_qkv_rows=pack_rows, qkv_q_prescaled=self.q_prescaled)
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
