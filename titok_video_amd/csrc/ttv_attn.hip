@@ -510,9 +510,12 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   TtvProfScope prof(TTV_KC_ATTENTION, s);
   if (dtype == TTV_BF16) {
     const float c_exp = scale * 1.44269504088896340736f;
+    // pre-scaled q: the exponent factor is 1; the accumulator-carried maximum (PRE) is built for the 4-wave kernel only - the paired
+    // kernel is held to 128 VGPRs and would spill its start vector - so paired launches run the generic softmax with factor 1
+    const float c_eff = prescaled ? 1.0f : c_exp;
 #define ATTN_LAUNCH(G_, NE_, P_, grid_, threads_)                                                                                   \
-  hipLaunchKernelGGL((k_attn_bf16<G_, NE_, P_>), grid_, dim3(threads_), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, \
-                     qblocks, n_qblocks, d_model, gqa, rep, c_exp, lse_out)
+  hipLaunchKernelGGL((k_attn_bf16<G_, NE_, (P_) && (NE_) == 1>), grid_, dim3(threads_), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, \
+                     cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_eff, lse_out)
 #define ATTN_PICK(NE_, grid_, threads_)                                                  \
   do {                                                                                   \
     if (gate_mul) { if (prescaled) ATTN_LAUNCH(true, NE_, true, grid_, threads_); else ATTN_LAUNCH(true, NE_, false, grid_, threads_); }   \
