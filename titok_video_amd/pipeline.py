@@ -14,7 +14,9 @@ benchmark batch (32 clips of 16x128x128, tiny): 20.9 k clips/s one batch at a ti
         ...
         recon, out = pipe.result(ticket)         # makes the CURRENT stream wait for that batch (no host sync)
 
-Not for the training step: there every step depends on the weights the previous one produced.
+Not for the training step: there every step depends on the weights the previous one produced.  Call `drain()` before the model's
+weights are modified (optimizer step, load_state_dict): the packed weight copies of a tower are rebuilt when a parameter changes and
+the old copies must not be released while a batch that reads them is still in flight.
 """
 from __future__ import annotations
 
