@@ -378,8 +378,10 @@ def test_attention_varlen_gqa_gate(dt, case, heads, split, paired, qscaled):
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_attention_online_softmax_rescale_branch(split):
-    """Force the running max to jump at a late key tile (spike one key against every query)."""
+@pytest.mark.parametrize("qscaled", [0, 4])
+def test_attention_online_softmax_rescale_branch(split, qscaled):
+    """Force the running max to jump at a late key tile (spike one key against every query); with pre-scaled q the maximum lives
+    inside the MFMA accumulator and the jump shifts the tile's scores, the running sums and the start vector."""
     plan = BatchPlan([(8, 32, 32)], [7], (4, 8, 8), DEV)   # S = 39 ... use a longer one
     plan = BatchPlan([(16, 64, 64)], [9], (4, 8, 8), DEV)  # S = 265 -> 5 key tiles
     hq, hkv, d, gq = 4, 2, 256, 128
@@ -388,12 +390,15 @@ def test_attention_online_softmax_rescale_branch(split):
     x = torch.randn(plan.total_rows, ld, generator=g) * 0.5
     q = x[:, :d].view(-1, 4, 64)
     x[200, 2 * d: 2 * d + gq] = 6.0 * torch.sign(q[5, 0]).repeat(2)   # key 200 (4th tile) dominates
+    q_f32 = x[:, :d].clone()
     x = x.to(torch.bfloat16)
     out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
     xd = x.to(DEV)
+    if qscaled:
+        xd[:, :d] = (q_f32 * (0.125 * 1.4426950408889634)).to(torch.bfloat16).to(DEV)
     tab = plan.attention_table(hq, hkv, split)
     _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
-                                 tab.shape[0], hq, hkv, 64, 0, _lib.TTV_BF16, S()), "attention")
+                                 tab.shape[0], hq, hkv, 64, qscaled, _lib.TTV_BF16, S()), "attention")
     f = x.float()
     qq, gt, k, v = f.split([d, d, gq, gq], dim=-1)
     ref = O.attention_varlen(qq.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)
