@@ -187,6 +187,9 @@ typedef struct ttv_layer_weights {
    * head_dim^-0.5 * log2(e): the projection then emits the softmax exponent directly and the attention kernel runs with
    * TTV_ATTN_QSCALED (one multiply-add less per score).  Inference towers only; `to_qkv` itself is never scaled. */
   int32_t qkv_q_prescaled;
+  /* optional (bf16, any width; used where to_qkv_pn is not): an inference copy of to_qkv whose q rows carry the same factor;
+   * NULL = use to_qkv and the plain attention kernel */
+  const void* to_qkv_qs;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {

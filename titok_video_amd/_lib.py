@@ -40,7 +40,8 @@ class NextQkv(C.Structure):
 
 class LayerWeights(C.Structure):
     _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
-                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("mlp_pack", vp), ("mlp_pack_qkv_rows", i32), ("qkv_q_prescaled", i32)]
+                ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("mlp_pack", vp), ("mlp_pack_qkv_rows", i32), ("qkv_q_prescaled", i32),
+                ("to_qkv_qs", vp)]
 
 
 class TowerWeights(C.Structure):

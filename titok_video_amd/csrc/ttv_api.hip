@@ -96,12 +96,13 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       GemmArgs a = {};
       a.dtype = dt;
       a.prenorm = fold_qkv; a.eps = d->eps;
-      a.x = fold_qkv ? ws.x : ws.xn; a.ldx = dm; a.w = fold_qkv ? lw.to_qkv_pn : lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+      const void* w_plain = (dt == TTV_BF16 && lw.to_qkv_qs) ? lw.to_qkv_qs : lw.to_qkv;   // inference copy with scaled q rows, if packed
+      a.x = fold_qkv ? ws.x : ws.xn; a.ldx = dm; a.w = fold_qkv ? lw.to_qkv_pn : w_plain; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
       a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
       TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     }
     // q arrives pre-scaled when the projection used the folded weight whose q rows carry scale * log2(e)
-    const bool q_scaled = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn && lw.qkv_q_prescaled;
+    const bool q_scaled = dt == TTV_BF16 && ((dm == 256 && lw.to_qkv_pn) ? lw.qkv_q_prescaled != 0 : lw.to_qkv_qs != nullptr);
     qkv_ready = false;
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0), dt, s));

@@ -248,8 +248,19 @@ class _WeightPack:
 
         # q rows of the folded QKV weight carry head_dim^-0.5 * log2(e): the projection then emits the softmax exponent and the
         # attention kernel saves a multiply-add per score (TTV_ATTN_QSCALED).  Applied in fp32 before the one rounding to bf16.
-        q_scale = 0.125 * 1.4426950408889634 if (fold and os.environ.get("TTV_ATTN_QSCALE", "1") != "0") else None
-        self.q_prescaled = 1 if q_scale is not None else 0
+        use_qs = dtype == torch.bfloat16 and os.environ.get("TTV_ATTN_QSCALE", "1") != "0"
+        q_scale = 0.125 * 1.4426950408889634 if use_qs else None
+        self.q_prescaled = 1 if (fold and use_qs) else 0
+
+        def lin_qs(w):
+            """Inference copy of to_qkv with the factor on its q rows, for towers whose QKV GEMM does not take the folded weight."""
+            if fold or not use_qs:
+                return None
+            t = w.detach().to(device=device, dtype=torch.float32).clone()
+            t[:tower.width] *= q_scale
+            t = t.to(dtype).contiguous()
+            keep.append(t)
+            return t.data_ptr()
 
         def folded_tensor(w, g, q_rows=0):
             t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
@@ -307,7 +318,7 @@ class _WeightPack:
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
                 ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
                 to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight, q_rows=tower.width), w12_pn=folded(f.w12.weight, f.norm.weight),
-                mlp_pack=pack_ptr, mlp_pack_qkv_rows=pack_rows, qkv_q_prescaled=self.q_prescaled)
+                mlp_pack=pack_ptr, mlp_pack_qkv_rows=pack_rows, qkv_q_prescaled=self.q_prescaled, to_qkv_qs=lin_qs(a.to_qkv.weight))
         self.struct = _lib.TowerWeights(
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
