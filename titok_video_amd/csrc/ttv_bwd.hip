@@ -416,24 +416,35 @@ __global__ __launch_bounds__(256) void k_gate_fwd(const T* __restrict__ a, int l
   }
 }
 // da = dag * sigmoid(gate);  dgate = dag * a * sigmoid(gate) * (1 - sigmoid(gate))
+// delta (optional, fp32 [rows, d/64]): the attention backward's delta[t, h] = sum over the head's 64 dims of da * a, taken from
+// the values this kernel holds anyway (da as it is stored, i.e. rounded to T) - 16 consecutive threads cover one (row, head).
 template <typename T>
 __global__ __launch_bounds__(256) void k_gate_bwd(const T* __restrict__ dag, int ldd, const T* __restrict__ a, int lda,
                                                   const T* __restrict__ gate, int ldg, T* __restrict__ da, int ldda, T* __restrict__ dgate,
-                                                  int lddg, int rows, int d) {
+                                                  int lddg, int rows, int d, float* __restrict__ delta) {
   const long total = (long)rows * (d / 4);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / (d / 4);
     const int c = (int)(i % (d / 4)) * 4;
     const f32x4 dv = Vec4<T>::load(dag + r * ldd + c), av = Vec4<T>::load(a + r * lda + c), gv = Vec4<T>::load(gate + r * ldg + c);
     f32x4 o1, o2;
+    float part = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float sg = sigmoidf_(gv[e]);
       o1[e] = dv[e] * sg;
       o2[e] = dv[e] * av[e] * sg * (1.0f - sg);
+      part = fmaf(round_to<T>(o1[e]), av[e], part);
     }
     Vec4<T>::store(da + r * ldda + c, o1);
     Vec4<T>::store(dgate + r * lddg + c, o2);
+    if (delta) {   // d % 64 == 0 (checked on the host): whole 16-lane groups are inside or outside the loop together
+      part += dpp_f(part, 0);
+      part += dpp_f(part, 1);
+      part += dpp_f(part, 2);
+      part += dpp_f(part, 3);
+      if ((threadIdx.x & 15) == 0) delta[r * (d >> 6) + (c >> 6)] = part;
+    }
   }
 }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -508,11 +519,12 @@ int ttvk_gate_fwd(const void* a, int lda, const void* gate, int ldg, void* ag, i
   return TTV_OK;
 }
 int ttvk_gate_bwd(const void* dag, int ldd, const void* a, int lda, const void* gate, int ldg, void* da, int ldda, void* dgate, int lddg,
-                  int rows, int d, int dt, hipStream_t s) {
+                  int rows, int d, int dt, float* delta, hipStream_t s) {
   if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(!delta || d % 64 == 0, "gate_bwd: delta needs whole 64-wide heads");
   const int nb = ew_blocks((long)rows * d / 4);
-  if (dt == TTV_BF16) hipLaunchKernelGGL((k_gate_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dag, ldd, (const bf16_t*)a, lda, (const bf16_t*)gate, ldg, (bf16_t*)da, ldda, (bf16_t*)dgate, lddg, rows, d);
-  else hipLaunchKernelGGL((k_gate_bwd<float>), dim3(nb), dim3(256), 0, s, (const float*)dag, ldd, (const float*)a, lda, (const float*)gate, ldg, (float*)da, ldda, (float*)dgate, lddg, rows, d);
+  if (dt == TTV_BF16) hipLaunchKernelGGL((k_gate_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dag, ldd, (const bf16_t*)a, lda, (const bf16_t*)gate, ldg, (bf16_t*)da, ldda, (bf16_t*)dgate, lddg, rows, d, delta);
+  else hipLaunchKernelGGL((k_gate_bwd<float>), dim3(nb), dim3(256), 0, s, (const float*)dag, ldd, (const float*)a, lda, (const float*)gate, ldg, (float*)da, ldda, (float*)dgate, lddg, rows, d, delta);
   TTV_CHECK_LAUNCH("gate_bwd");
   return TTV_OK;
 }
@@ -1439,11 +1451,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(const bf16_t* __restrict__ 
 // (fp32 path); dkv_scratch: fp32 [L, 2g] zeroed by this function (fp32 path only).
 int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                        const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
-                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s) {
+                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s, int delta_ready) {
   if (total_rows == 0) return TTV_OK;
   const float scale = 0.125f;
   const int d_model = hq * 64, gqa = hkv * 64;
-  if (dt == TTV_BF16) hipLaunchKernelGGL((k_attn_delta<bf16_t>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const bf16_t*)dout, ldd, (const bf16_t*)o, ldo, delta, total_rows, hq);
+  if (delta_ready) {
+    // the caller's gate backward already filled delta (same values: sum of the stored dO times O)
+  } else if (dt == TTV_BF16) hipLaunchKernelGGL((k_attn_delta<bf16_t>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const bf16_t*)dout, ldd, (const bf16_t*)o, ldo, delta, total_rows, hq);
   else hipLaunchKernelGGL((k_attn_delta<float>), dim3(ttv_cdiv(total_rows * hq, 256)), dim3(256), 0, s, (const float*)dout, ldd, (const float*)o, ldo, delta, total_rows, hq);
   TTV_CHECK_LAUNCH("attn_delta");
   if (dt == TTV_BF16) {

@@ -100,7 +100,7 @@ int ttvk_colsum(const void* a, int dt, int lda, const int* rows_map, int rows, i
 int ttvk_sumall(const void* a, int dt, int lda, const int* rows_map, int rows, int n, const float* colw, float scale, float* out, hipStream_t s);
 int ttvk_gate_fwd(const void* a, int lda, const void* gate, int ldg, void* ag, int ldo, int rows, int d, int dt, hipStream_t s);
 int ttvk_gate_bwd(const void* dag, int ldd, const void* a, int lda, const void* gate, int ldg, void* da, int ldda, void* dgate, int lddg,
-                  int rows, int d, int dt, hipStream_t s);
+                  int rows, int d, int dt, float* delta, hipStream_t s);
 int ttvk_geglu_fwd(const void* u, int ldu, void* h, int ldh, int rows, int I, int dt, hipStream_t s);
 int ttvk_geglu_bwd(const void* u, int ldu, const void* dh, int lddh, void* du, int lddu, int rows, int I, int dt, hipStream_t s);
 int ttvk_scale_cast(const float* a, float alpha, float* b, void* c, int dt, long n, hipStream_t s);
@@ -118,7 +118,7 @@ int ttvk_reduce_small(const void* a, int a_dt, int lda, const int* a_rows, const
                       int rows, int d, hipStream_t s);
 int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                        const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
-                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s);
+                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s, int delta_ready = 0);
 int ttvk_rope_apply_dir(void* x, int dtype, int ld, int rows, int heads, const float* cs, int conj, hipStream_t s);
 int ttvk_dec_embed_ex(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain, void* x,
                       int dtype, int ld, const int* rows_map, int rows, int d, float eps, void* hpre, hipStream_t s);

@@ -188,10 +188,11 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     // da = dag*sigmoid(gate) (into g_d) ; dgate -> dqkvg[:, d:2d]
     char* dqkvg = ws.g_nq;
     const size_t es = esz(dt);
-    TTV_TRY(ttvk_gate_bwd(ws.g_d2, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt, s));
+    TTV_TRY(ttvk_gate_bwd(ws.g_d2, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt,
+                          ws.delta, s));   // also fills delta = sum_d da * a per (row, head) for the attention backward
     // attention backward -> dq, dk, dv columns of dqkvg
     TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, ws.g_d, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
-                               ws.dkv, L, d->q_heads, d->kv_heads, dt, b->rope_cs, s));   // dq, dk come back un-rotated
+                               ws.dkv, L, d->q_heads, d->kv_heads, dt, b->rope_cs, s, 1));   // dq, dk come back un-rotated; delta from the gate backward
     // dxn1 = dqkvg Wqkv ; dWqkv += dqkvg^T xn1
     GemmArgs q = {};
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
