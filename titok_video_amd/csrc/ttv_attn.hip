@@ -39,7 +39,7 @@ template <bool GATE, int NE, bool PRE>
 __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
                                                            const int* __restrict__ cu, const int* __restrict__ qblocks, int n_entries,
                                                            int d_model, int gqa, int rep, float c_exp /* scale*log2(e) */,
-                                                           float* __restrict__ lse_out) {
+                                                           float* __restrict__ lse_out, bf16_t* __restrict__ out_raw) {
   __shared__ __attribute__((aligned(16))) uint4 kl[2][KB * 8];
   __shared__ __attribute__((aligned(16))) uint4 vl[2][KB * 8];
   __shared__ float xm_s[NE * 2 * 2 * 64];       // half items: (m, l) hand-over of the second wave pair of each entry
@@ -403,6 +403,11 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
       for (int g = 0; g < 4; ++g) {
         const int d0 = dt * 32 + 8 * g + 4 * h;
         f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+        if (out_raw) {   // training tape: the ungated output as well; the gate then multiplies the stored (rounded) value
+          Vec4<bf16_t>::store(out_raw + (size_t)(s0 + qrow) * ldo + head * 64 + d0, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = round_to<bf16_t>(v[e]);
+        }
         if (GATE) {
           const f32x4 gt = Vec4<bf16_t>::load(grow + d0);
 #pragma unroll
@@ -495,10 +500,12 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg
 }
 
 // flags: bit 0 (TTV_ATTN_GATE) multiply by sigmoid(gate); bit 1 (TTV_ATTN_PAIRED) the table is paired (see k_attn_bf16, NE = 2)
+// out_raw (bf16 only, with TTV_ATTN_GATE; leading dimension ldo): additionally receives the UNGATED attention output
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
-                   int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out) {
+                   int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out, void* out_raw) {
   const int gate_mul = flags & 1, paired = (flags >> 1) & 1, prescaled = (flags >> 2) & 1;
   TTV_CHECK_ARG(!prescaled || dtype == TTV_BF16, "attention: pre-scaled q is a bf16 path option");
+  TTV_CHECK_ARG(!out_raw || (dtype == TTV_BF16 && gate_mul), "attention: the second (ungated) output is a bf16 + gate option");
   if (n_qblocks == 0) return TTV_OK;
   TTV_CHECK_ARG(head_dim == 64, "attention: head_dim %d unsupported (the reference fixes 64, utils.py:8)", head_dim);
   TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention: q_heads %% kv_heads");
@@ -515,7 +522,7 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
     const float c_eff = prescaled ? 1.0f : c_exp;
 #define ATTN_LAUNCH(G_, NE_, P_, grid_, threads_)                                                                                   \
   hipLaunchKernelGGL((k_attn_bf16<G_, NE_, (P_) && (NE_) == 1>), grid_, dim3(threads_), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, \
-                     cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_eff, lse_out)
+                     cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_eff, lse_out, (bf16_t*)out_raw)
 #define ATTN_PICK(NE_, grid_, threads_)                                                  \
   do {                                                                                   \
     if (gate_mul) { if (prescaled) ATTN_LAUNCH(true, NE_, true, grid_, threads_); else ATTN_LAUNCH(true, NE_, false, grid_, threads_); }   \

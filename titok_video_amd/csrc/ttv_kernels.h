@@ -69,7 +69,8 @@ bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 
 // ---- ttv_attn.hip ----
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
-                   int q_heads, int kv_heads, int head_dim, int gate_mul, int dtype, hipStream_t s, float* lse_out = nullptr);
+                   int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out = nullptr,
+                   void* out_raw = nullptr);
 
 // ---- ttv_mlp.hip ----
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner);

@@ -104,9 +104,15 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     a.dtype = dt; a.x = l.xn1; a.ldx = dm; a.w = lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = l.qkvg; a.ldy = nq;
     a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
     TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
-    TTV_TRY(ttvk_attention(l.qkvg, nq, l.a, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
-                           b->qblocks_paired ? TTV_ATTN_PAIRED : 0, dt, s, l.lse));
-    TTV_TRY(ttvk_gate_fwd(l.a, dm, (const char*)l.qkvg + (size_t)dm * esz(dt), nq, l.ag, dm, L, dm, dt, s));
+    if (dt == TTV_BF16) {
+      // one launch writes the raw output a (tape) and the gated one ag = a * sigmoid(gate) (gate applied to the stored, rounded a)
+      TTV_TRY(ttvk_attention(l.qkvg, nq, l.ag, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
+                             TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0), dt, s, l.lse, l.a));
+    } else {
+      TTV_TRY(ttvk_attention(l.qkvg, nq, l.a, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
+                             b->qblocks_paired ? TTV_ATTN_PAIRED : 0, dt, s, l.lse));
+      TTV_TRY(ttvk_gate_fwd(l.a, dm, (const char*)l.qkvg + (size_t)dm * esz(dt), nq, l.ag, dm, L, dm, dt, s));
+    }
     GemmArgs o = {};
     o.dtype = dt; o.x = l.ag; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = t.X[i]; o.ldr = dm;
     if (i == 0) {
