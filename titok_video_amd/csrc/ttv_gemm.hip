@@ -123,6 +123,22 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
         }
     }
   } else if (EPI == EPI_GEGLU) {
+    if (p.resid) {
+      // training tape: the pre-activations u = [x | gate] (ld = ldr) are kept as well; h is then formed from the STORED (rounded)
+      // values, exactly what a separate GEGLU pass over u would see
+      T* u = (T*)const_cast<void*>(p.resid);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (tv[j] && fv[i]) {
+            Vec4<T>::store(u + (size_t)tok[j] * p.ldr + feat[i], acc[i][j]);
+            Vec4<T>::store(u + (size_t)tok[j] * p.ldr + p.N + feat[i], acc2[i][j]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[i][j][e] = round_to<T>(acc[i][j][e]); acc2[i][j][e] = round_to<T>(acc2[i][j][e]); }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll

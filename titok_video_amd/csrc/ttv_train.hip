@@ -125,9 +125,16 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     }
     TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
-    f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = 2 * I; f.K = dm; f.y = l.u; f.ldy = 2 * I;
-    TTV_TRY(ttvk_gemm(EPI_STORE, f, s));
-    TTV_TRY(ttvk_geglu_fwd(l.u, 2 * I, l.h, I, L, I, dt, s));
+    if (dt == TTV_BF16) {
+      // one launch: u = xn2 W12^T kept for the backward (through `resid`) and h = gelu(gate) * x from the stored values
+      f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = I; f.K = dm; f.y = l.h; f.ldy = I;
+      f.resid = l.u; f.ldr = 2 * I;
+      TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
+    } else {
+      f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = 2 * I; f.K = dm; f.y = l.u; f.ldy = 2 * I;
+      TTV_TRY(ttvk_gemm(EPI_STORE, f, s));
+      TTV_TRY(ttvk_geglu_fwd(l.u, 2 * I, l.h, I, L, I, dt, s));
+    }
     GemmArgs f3 = {};
     f3.dtype = dt; f3.x = l.h; f3.ldx = I; f3.w = lw.w3; f3.ldw = I; f3.M = L; f3.N = dm; f3.K = I; f3.resid = l.x1; f3.ldr = dm;
     if (i == 0) {
