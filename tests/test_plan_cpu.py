@@ -115,3 +115,27 @@ def test_fsq_module_constants_match_reference_module_api():
     assert list(f.state_dict().keys()) == []
     with pytest.raises(RuntimeError):
         f(z)          # CPU tensor: the hot path has no fallback
+
+
+def test_bench_flop_accounting_matches_the_survey():
+    """bench.py's algorithmic FLOP figures: 26.475 GFLOP per clip for tiny/tiny at K = 128, attention
+    4 S^2 d per layer-tower launch over the batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    S, P, K = 1152, 1024, 128
+    assert abs(bench.tower_flops_per_clip(S, P, K) - 2.6475e10) / 2.6475e10 < 1e-3
+    assert bench.kernel_flops_per_launch("attention", 32, S) == 32 * 4 * S * S * 256
+
+
+def test_forward_pipeline_needs_a_gpu_model():
+    from types import SimpleNamespace
+    from titok_video_amd.model.titok import TiTok
+    from titok_video_amd.pipeline import ForwardPipeline
+    cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5],
+                                                                          encoder_size="tiny", decoder_size="tiny")))
+    with pytest.raises(RuntimeError):
+        ForwardPipeline(TiTok(cfg), depth=2)
+    with pytest.raises(ValueError):
+        ForwardPipeline(TiTok(cfg), depth=0)
