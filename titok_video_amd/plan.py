@@ -184,7 +184,8 @@ class BatchPlan:
         6144-token training batches) the last third of every sequence's query blocks is issued as half items and the launch
         gets shorter (5 clips: 33 -> 27 us).  Larger grids keep full items: with a second batch in flight (pipeline.py) the
         tail of one launch is filled by the other chain and the extra work of half items only costs (-3 % measured), alone
-        they are worth +1 %.  Within either regime the choice depends only on the sequence's own length, so a clip's bf16
+        they are worth +1 % (TTV_ATTN_TAIL_DIV=8 halves the last eighth of every sequence's blocks on large grids: exactly
+        the 128 items beyond 1024 slots at the benchmark batch, +1.5 % one batch at a time, -1 % with two in flight).  Within either regime the choice depends only on the sequence's own length, so a clip's bf16
         result does not depend on what it is packed with (the fp32 kernel computes the same way in both modes).
         `split`: None = that rule, False = never, True = every item (tests)."""
         if split is None and os.environ.get("TTV_ATTN_SPLIT") in ("0", "1"):      # diagnostics: A/B timing of the table kinds
@@ -199,7 +200,8 @@ class BatchPlan:
             for b in range(len(self.grids)):
                 s = self.cu_seqlens[b + 1] - self.cu_seqlens[b]
                 nq = -(-s // QBLOCK)
-                first_half = 0 if split else (nq if (split is False or not small_grid) else nq - nq // 3)
+                tail_div = 3 if small_grid else int(os.environ.get("TTV_ATTN_TAIL_DIV", "0"))
+                first_half = 0 if split else (nq if (split is False or tail_div <= 0) else nq - nq // tail_div)
                 for kvh in range(kv_heads):
                     heads = [kvh * rep + r for r in range(rep)]
                     units_full.append([(b, qb * QBLOCK, hd, 0) for qb in range(first_half) for hd in heads])
