@@ -314,3 +314,29 @@ def test_forward_pipeline_matches_sequential_calls():
             assert torch.equal(a, b)
     # the two streams really use separate scratch buffers
     assert len({k[2] for k in model.encoder._ws}) >= 2
+
+
+def test_sampling_range_extremes_fp32_match_oracle():
+    """The corners of the reference's sampling ranges (configs/tiny.yaml:57-62): the largest grid 16x168x168 (21x21 patches per
+    frame group: not a power of two, 1764 patches) with the most (128) and the fewest (1) latent tokens, next to the smallest
+    grid 8x128x128.  fp32 path against the oracle: indices bit-exact away from rounding boundaries, pixels to 5e-3."""
+    shapes, counts = [(16, 168, 168), (8, 128, 128), (16, 168, 168)], [128, 1, 1]
+    clips = synthetic_clips(shapes, seed=77, dtype=torch.float32, device=DEV)
+    model = build(torch.float32)
+    with torch.no_grad():
+        codes, od = model.encode(clips, counts, want_bounded=True)
+        recon = model.decode(codes, counts, shapes)
+    sd = seeded_titok_state(0)
+    ref_recon, ref_idx, _ref_z, ref_bounded = O.titok_forward([c.cpu() for c in clips], counts, sd, LEVELS)
+    idx = od["indices"].cpu()
+    assert idx.shape == (130,)
+    safe = O.fsq_margin(ref_bounded) > TAU_F32
+    assert int(safe.sum()) >= 120
+    assert torch.equal(idx[safe], ref_idx[safe])
+    np.testing.assert_allclose(model.last_bounded.cpu().numpy(), ref_bounded.numpy(), rtol=0, atol=2e-3)
+    for r, ref in zip(recon, ref_recon):
+        assert r.shape == ref.shape
+        # decoder inputs are the same codes wherever the indices agree; compare through the oracle's decode of OUR indices
+    dec_ref = O.titok_decode_indices(idx, shapes, counts, sd, LEVELS)
+    for r, ref in zip(recon, dec_ref):
+        np.testing.assert_allclose(r.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-3)
