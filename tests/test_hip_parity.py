@@ -340,3 +340,24 @@ def test_sampling_range_extremes_fp32_match_oracle():
     dec_ref = O.titok_decode_indices(idx, shapes, counts, sd, LEVELS)
     for r, ref in zip(recon, dec_ref):
         np.testing.assert_allclose(r.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-3)
+
+
+def test_sampling_range_extremes_bf16_close_to_oracle():
+    """Same corners through the bf16 kernels (fused tail, gathered proj_in, scattered proj_out, LDS-DMA attention with an odd
+    number of key tiles): indices exact wherever the fp32 value is further from a rounding boundary than the observed error."""
+    shapes, counts = [(16, 168, 168), (8, 128, 128), (16, 168, 168)], [128, 1, 1]
+    clips32 = synthetic_clips(shapes, seed=77, dtype=torch.float32, device="cpu")
+    model = build(torch.bfloat16)
+    clips = [c.to(DEV, torch.bfloat16) for c in clips32]
+    with torch.no_grad():
+        codes, od = model.encode(clips, counts, want_bounded=True)
+        recon = model.decode(codes, counts, shapes)
+    sd = seeded_titok_state(0)
+    _r, ref_idx, _z, ref_bounded = O.titok_forward([c.to(torch.bfloat16).float() for c in clips32], counts, sd, LEVELS)
+    berr = float((model.last_bounded.float().cpu() - ref_bounded).abs().max())
+    safe = O.fsq_margin(ref_bounded) > berr + 1e-6
+    assert berr < 0.6
+    assert torch.equal(od["indices"].cpu()[safe], ref_idx[safe])
+    dec_ref = O.titok_decode_indices(od["indices"].cpu(), shapes, counts, sd, LEVELS)
+    for r, ref in zip(recon, dec_ref):
+        assert float((r.float().cpu() - ref).abs().max()) < PIX_TOL_BF16 * 1.5
