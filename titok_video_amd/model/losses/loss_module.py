@@ -45,73 +45,70 @@ class ReconstructionLoss(nn.Module):
         self.centering_weight = float(loss_d.centering_weight)
         self.total_steps = config.training.main.max_steps
 
+    # ---- discriminator access -------------------------------------------------------------------------------------------
     def disc_wrapper(self, x: Sequence[torch.Tensor]) -> torch.Tensor:
-        """[B] logits = mean over each clip's 4 register tokens (loss_module.py:96-101)."""
-        b = len(x)
-        logits = self.disc_model(list(x), [self.disc_tokens] * b).view(b, -1).mean(-1)
-        return logits
+        """One logit per clip: the mean of the clip's 4 register-token outputs (loss_module.py:96-101)."""
+        n = len(x)
+        per_token = self.disc_model(list(x), [self.disc_tokens] * n)          # [4 n, 1]
+        return per_token.view(n, -1).mean(dim=-1)
+
+    def _set_disc_trainable(self, flag: bool) -> None:
+        for p in self.disc_model.parameters():
+            p.requires_grad = flag
+
+    @staticmethod
+    def _report(prefix: str, terms) -> dict:
+        """The reference's logging dictionary: every term reduced to a detached scalar under 'gen/..' or 'disc/..'."""
+        return {f"{prefix}/{name}": value.clone().mean().detach() for name, value in terms.items()}
 
     def forward(self, target, recon, disc_forward: bool = False, gp_noise_tensors: Optional[List[torch.Tensor]] = None):
         if disc_forward:
-            return self._forward_discriminator(target, recon, gp_noise_tensors)
-        return self._forward_generator(target, recon)
+            return self._discriminator_step_loss(target, recon, gp_noise_tensors)
+        return self._generator_step_loss(target, recon)
 
-    def _forward_generator(self, target, recon):
-        loss_dict = {}
-        target = [i.contiguous() for i in target]
-        recon = [i.contiguous() for i in recon]
+    # ---- generator step (loss_module.py:110-162, perceptual terms off) ----------------------------------------------------
+    def _generator_step_loss(self, target, recon):
+        real = [t.contiguous() for t in target]
+        fake = [r.contiguous() for r in recon]
         # mean over clips of the per-clip L1 means (loss_module.py:118; value and gradient in one HIP launch).  The reference keeps
         # the [B] vector until the final .mean(); mean(a + w b) = mean(a) + w mean(b), so the scalar is carried instead.
-        recon_loss = l1_reconstruction_loss(recon, target)
-        loss_dict["recon_loss"] = recon_loss
-        g_loss = 0.0
+        terms = {"recon_loss": l1_reconstruction_loss(fake, real)}
+        total = terms["recon_loss"]
         if self.disc_weight > 0.0:
-            target = [i.detach().contiguous() for i in target]
-            for param in self.disc_model.parameters():                 # loss_module.py:144-146
-                param.requires_grad = False
-            logits_real = self.disc_wrapper(target)
-            logits_fake = self.disc_wrapper(recon)
-            logits_relative = logits_fake - logits_real
-            g_loss = F.softplus(-logits_relative)
-            loss_dict["g_loss"] = g_loss
-        total_loss = recon_loss + (self.disc_weight * g_loss.mean() if self.disc_weight > 0.0 else 0.0)
-        loss_dict["total_loss"] = total_loss
-        return total_loss, {"gen/" + k: v.clone().mean().detach() for k, v in loss_dict.items()}
+            self._set_disc_trainable(False)                                   # the generator sees a frozen critic (:144-146)
+            score_real = self.disc_wrapper([t.detach() for t in real])        # no gradient path: runs the fused inference towers
+            score_fake = self.disc_wrapper(fake)                              # tape + inputs-only backward into the reconstruction
+            terms["g_loss"] = F.softplus(score_real - score_fake)             # softplus(-(fake - real)), relativistic (:149-151)
+            total = total + self.disc_weight * terms["g_loss"].mean()
+        terms["total_loss"] = total
+        return total, self._report("gen", terms)
 
-    def _forward_discriminator(self, target, recon, noise=None):
-        loss_dict = {}
-        target = [i.detach().requires_grad_(True).contiguous() for i in target]
-        recon = [i.detach().requires_grad_(True).contiguous() for i in recon]
-        for param in self.disc_model.parameters():                     # loss_module.py:172-174
-            param.requires_grad = True
+    # ---- discriminator step (loss_module.py:165-213) ----------------------------------------------------------------------
+    def _discriminator_step_loss(self, target, recon, noise=None):
+        real = [t.detach().requires_grad_(True).contiguous() for t in target]  # as upstream (:168-169)
+        fake = [r.detach().requires_grad_(True).contiguous() for r in recon]
+        self._set_disc_trainable(True)
+        use_penalty = self.gp_weight > 0.0
         # The reference makes 2 (+2 with the penalty) discriminator calls; clips are independent inside the tower (block-diagonal
         # attention, per-row norms), so they are issued here as ONE packed call and the logits split afterwards: same values,
         # one tape / one backward / one set of weight-gradient launches instead of four.
-        b = len(target)
-        batch = list(target) + list(recon)
-        if self.gp_weight > 0.0:                                       # finite-difference R1 / R2 (loss_module.py:187-198)
+        packed = real + fake
+        if use_penalty:
             if noise is None:
-                noise = [torch.randn_like(x) * self.gp_noise for x in target]
-            batch += [x + y for x, y in zip(target, noise)] + [x + y for x, y in zip(recon, noise)]
-        logits = self.disc_wrapper(batch)
-        logits_real, logits_fake = logits[:b], logits[b:2 * b]
-        logits_relative = logits_real - logits_fake
-        d_loss = F.softplus(-logits_relative)
-        loss_dict["d_loss"] = d_loss
-        loss_dict["logits_relative"] = logits_relative
-        gradient_penalty = 0.0
-        if self.gp_weight > 0.0:
-            logits_real_noised, logits_fake_noised = logits[2 * b:3 * b], logits[3 * b:]
-            r1_penalty = (logits_real - logits_real_noised) ** 2
-            r2_penalty = (logits_fake - logits_fake_noised) ** 2
-            loss_dict["r1_penalty"] = r1_penalty
-            loss_dict["r2_penalty"] = r2_penalty
-            gradient_penalty = r1_penalty + r2_penalty
-        centering_loss = 0.0
-        if self.centering_weight > 0.0:
-            centering_loss = ((logits_real + logits_fake) ** 2) / 2
-            loss_dict["centering_loss"] = centering_loss
-        total_loss = (d_loss + (self.gp_weight / self.gp_noise ** 2 * gradient_penalty)
-                      + (self.centering_weight * centering_loss)).mean()
-        loss_dict["total_loss"] = total_loss
-        return total_loss, {"disc/" + k: v.clone().mean().detach() for k, v in loss_dict.items()}
+                noise = [torch.randn_like(t) * self.gp_noise for t in real]
+            packed = packed + [t + e for t, e in zip(real, noise)] + [f + e for f, e in zip(fake, noise)]
+        scores = self.disc_wrapper(packed).view(-1, len(real))                # rows: real, fake, (real + noise, fake + noise)
+        score_real, score_fake = scores[0], scores[1]
+        margin = score_real - score_fake
+        terms = {"d_loss": F.softplus(-margin), "logits_relative": margin}
+        total = terms["d_loss"]
+        if use_penalty:                                                       # finite-difference R1 / R2 (:187-198)
+            terms["r1_penalty"] = (score_real - scores[2]).square()
+            terms["r2_penalty"] = (score_fake - scores[3]).square()
+            total = total + (self.gp_weight / self.gp_noise ** 2) * (terms["r1_penalty"] + terms["r2_penalty"])
+        if self.centering_weight > 0.0:                                       # keeps real / fake logits centred on zero (:201-204)
+            terms["centering_loss"] = 0.5 * (score_real + score_fake).square()
+            total = total + self.centering_weight * terms["centering_loss"]
+        total = total.mean()
+        terms["total_loss"] = total
+        return total, self._report("disc", terms)
