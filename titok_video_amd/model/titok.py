@@ -20,55 +20,58 @@ from .quantizer.fsq import FSQ
 
 
 class TiTok(nn.Module):
+    """encoder -> FSQ -> decoder over lists of [3,T,H,W] clips; parameters live in `encoder.*` and `decoder.*`."""
+
     def __init__(self, config):
         super().__init__()
         self.config = config
-        conf = config.tokenizer.model
-        levels = list(conf.fsq_levels)
-        token_size = len(levels)
-        patch = tuple(int(p) for p in conf.patch_size)
-        self.encoder = TiTokEncoder(model_size=conf.encoder_size, patch_size=patch, in_channels=3, out_channels=token_size)
-        self.quantize = FSQ(levels=levels)
-        self.decoder = TiTokDecoder(model_size=conf.decoder_size, patch_size=patch, in_channels=token_size, out_channels=3)
+        m = config.tokenizer.model
+        fsq_levels = [int(v) for v in m.fsq_levels]
+        patch = tuple(int(p) for p in m.patch_size)
+        n_code = len(fsq_levels)                       # one latent channel per FSQ level
+        towers = dict(encoder=TiTokEncoder(model_size=m.encoder_size, patch_size=patch, in_channels=3, out_channels=n_code),
+                      quantize=FSQ(levels=fsq_levels),
+                      decoder=TiTokDecoder(model_size=m.decoder_size, patch_size=patch, in_channels=n_code, out_channels=3))
+        for name, mod in towers.items():               # registration order = the reference's state-dict order
+            setattr(self, name, mod)
         self.apply(init_weights)
         self.last_bounded = None   # fp32 FSQ pre-rounding values of the last encode(want_bounded=True)
+
+    # ---- encode ---------------------------------------------------------------------------------------------------------
+    def _encode_differentiable(self, clips, counts, grids, split_indices):
+        """Training step (train.py:65-83): tape-recording towers with the HIP backward, straight-through FSQ."""
+        z = self.encoder.forward_z(clips, counts, grids)               # fp32, carries the autograd graph
+        codes, info = self.quantize(z)
+        self.last_bounded = None
+        if split_indices:
+            info["indices"] = torch.split(info["indices"], counts, dim=0)
+        return codes.to(clips[0].dtype), info
 
     def encode(self, x, token_counts, grids=None, split_indices=False, want_bounded=False):
         counts = host_ints(token_counts)
         if self.encoder._wants_grad(*x):
-            # training step (train.py:65-83): differentiable towers (tape + HIP backward) and straight-through FSQ
-            z = self.encoder.forward_z(x, counts, grids)                 # fp32, carries the autograd graph
-            codes, x_dict = self.quantize(z)
-            self.last_bounded = None
-            if split_indices:
-                x_dict["indices"] = torch.split(x_dict["indices"], counts, dim=0)
-            return codes.to(x[0].dtype), x_dict
-        out = self.encoder.run(x, counts, grids, self.quantize.params, want_z=False, want_bounded=want_bounded)
-        self.last_bounded = out["bounded"]
-        indices = out["indices"]
-        if split_indices:
-            indices = torch.split(indices, counts, dim=0)
-        return out["codes"], {"indices": indices}
+            return self._encode_differentiable(x, counts, grids, split_indices)
+        res = self.encoder.run(x, counts, grids, self.quantize.params, want_z=False, want_bounded=want_bounded)
+        self.last_bounded = res["bounded"]
+        idx = torch.split(res["indices"], counts, dim=0) if split_indices else res["indices"]
+        return res["codes"], {"indices": idx}
 
-    def decode_indices(self, indices, grids, token_counts=None):
-        if token_counts is None:
-            assert type(indices) in [list, tuple]
-            token_counts = [int(t.shape[0]) for t in indices]
-            indices = torch.cat(list(indices), dim=0)
-        # reference: decoder parameter dtype (titok.py:61); under autocast (Lightning bf16-mixed, fp32 masters)
-        # the towers compute in the autocast dtype, so follow it
-        dtype = next(self.decoder.parameters()).dtype
-        if torch.is_autocast_enabled():
-            dtype = torch.get_autocast_gpu_dtype()
-        x_q = self.quantize.indices_to_codes(indices, dtype=dtype)
-        return self.decoder(x_q, token_counts, grids)
-
+    # ---- decode ---------------------------------------------------------------------------------------------------------
     def decode(self, x, token_counts, grids):
         return self.decoder(x, token_counts, grids)
 
+    def decode_indices(self, indices, grids, token_counts=None):
+        if token_counts is None:                        # per-clip index tensors (titok.py:54-58)
+            assert type(indices) in [list, tuple]
+            token_counts = [int(part.shape[0]) for part in indices]
+            indices = torch.cat(list(indices), dim=0)
+        # reference: decoder parameter dtype (titok.py:61); under autocast (Lightning bf16-mixed, fp32 masters)
+        # the towers compute in the autocast dtype, so follow it
+        compute_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else next(self.decoder.parameters()).dtype
+        return self.decode(self.quantize.indices_to_codes(indices, dtype=compute_dtype), token_counts, grids)
+
     def forward(self, x, token_counts):
-        grids = [tuple(im.shape[1:]) for im in x]     # host ints; the reference builds a device tensor (titok.py:70)
+        pixel_grids = [tuple(clip.shape[1:]) for clip in x]     # host ints; the reference builds a device tensor (titok.py:70)
         counts = host_ints(token_counts)
-        x_q, out_dict = self.encode(x, counts, grids)
-        recon = self.decode(x_q, counts, grids)
-        return recon, out_dict
+        codes, info = self.encode(x, counts, pixel_grids)
+        return self.decode(codes, counts, pixel_grids), info
