@@ -155,7 +155,7 @@ def main():
             model(clips, counts)
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, args.in_flight)):     # at least one untimed pass per stream (workspace, plan, weight pack)
             step()
         lib = _lib.lib()
         launches_per_step = 8     # 4 layers x 2 towers
