@@ -17,7 +17,8 @@ TTV_MAX_FSQ = 8
 TTV_MAX_CLIPS_PER_LAUNCH = 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtitok_hip.so")
+# TTV_LIB_PATH: diagnostics only (an instrumented build of the same sources, tools/attn_stamps.py)
+LIB_PATH = os.environ.get("TTV_LIB_PATH") or os.path.join(_HERE, "libtitok_hip.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

@@ -12,12 +12,16 @@
 // Online softmax in fp32 (exp2 with the scale folded into one FMA); output is normalised, multiplied by
 // sigmoid(gate) and stored as 4 consecutive head dims per lane.
 //
-// fp32 kernel: parity instrument (the reference never runs fp32 attention on GPU); one wave per query, 64 keys per step.
+// fp32 kernel: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), same block decomposition; see k_attn_f32.
+#include <stdlib.h>
+
 #include "ttv_common.h"
 #include "ttv_kernels.h"
 
 #define QB 128
 #define KB 64
+// online softmax: the running reference of a query row moves only when a score exceeds it by more than this (log2 units)
+#define ATTN_DEFER_THR 8.0f
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -27,6 +31,32 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds_ptr));
 }
 
+// Diagnostic build only (-DATTN_STAMPS, tools/attn_stamps.py): s_memtime stamps at the segment boundaries of the key loop of full
+// items, summed per wave over the loop and written by every 37th block to stamps[(block / 37) * 4 + wave][8].  The product
+// library is built without it (no stamp executes, no fence constrains the scheduler).
+#ifdef ATTN_STAMPS
+#define STAMP_DECL unsigned long long st_prev__ = 0, st_acc__[6] = {0, 0, 0, 0, 0, 0}
+#define STAMP_START()                                                                                  \
+  do {                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev__)::"memory");                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+#define STAMP(seg_)                                                                                    \
+  do {                                                                                                 \
+    unsigned long long t__;                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    st_acc__[seg_] += t__ - st_prev__;                                                                 \
+    st_prev__ = t__;                                                                                   \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_START()
+#define STAMP(seg_)
+#endif
+
 // NE = table entries per block.  NE == 2 ("paired" tables, plan.attention_table): a block of 8 waves takes entries 2j and 2j+1 of
 // its XCD list - the same query rows of the two q-heads that share a kv-head - so every K / V tile is staged ONCE for both heads
 // (half the tile traffic through L2 and LDS per score).  Waves 0-3 work on the first entry, 4-7 on the second, exactly as the
@@ -35,11 +65,24 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 // ttv_layer_weights.qkv_q_prescaled): S is then already the exponent.  The running maximum is carried INSIDE the MFMA accumulator -
 // the score tiles start from -m instead of 0 - so a score needs no multiply-subtract before its exp2 (4 instead of 5 issue slots);
 // when a tile raises the maximum (rare after the first tiles) the tile's scores, the running state and the start vector are shifted.
-template <bool GATE, int NE, bool PRE>
-__global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
+// TAPE: the training forward - additionally writes the log-sum-exp per (row, head) and, with the gate, the ungated output.
+//
+// VALU budget.  The kernel is bound by the vector issue port (SQ_ACTIVE_INST_VALU ~ 80 % of the wave-cycles at three waves per
+// SIMD, profiles/r02_attn_sq_*.csv), so everything that is not an exp2, a bf16 pack or an MFMA has been moved off it:
+//   * row sums ride on the matrix pipe: a third O^T tile whose V^T operand is a constant "ones" row (A[row 0][k] = 1) accumulates
+//     l = sum_k P[k][q] in its row 0 - 4 extra MFMAs per tile (the pipe is < 40 % busy) instead of 32 v_add_f32, and the sum is
+//     taken over the same bf16-rounded P that enters the numerator;
+//   * the running reference of the softmax moves only when a score exceeds it by more than `defer_thr` (see below);
+//   * the DMA source of a tile is a scalar base (advanced per tile on the scalar unit) plus lane-constant offsets: no per-tile
+//     address arithmetic on the vector unit except in a sequence's last, partial tile;
+//   * the epilogue uses v_rcp_f32 for 1/l and the sigmoid (a full-precision division is ~10 instructions per element and the
+//     epilogue was a quarter of the wave's vector instructions) and stores 16 bytes per lane (lanes l, l+32 exchange 8-byte
+//     groups with v_permlane32_swap).
+template <bool GATE, int NE, bool PRE, bool TAPE>
+__global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
                                                            const int* __restrict__ cu, const int* __restrict__ qblocks, int n_entries,
                                                            int d_model, int gqa, int rep, float c_exp /* scale*log2(e) */,
-                                                           float* __restrict__ lse_out, bf16_t* __restrict__ out_raw) {
+                                                           float* __restrict__ lse_out, bf16_t* __restrict__ out_raw, float defer_thr, long long* __restrict__ stamps) {
   __shared__ __attribute__((aligned(16))) uint4 kl[2][KB * 8];
   __shared__ __attribute__((aligned(16))) uint4 vl[2][KB * 8];
   __shared__ float xm_s[NE * 2 * 2 * 64];       // half items: (m, l) hand-over of the second wave pair of each entry
@@ -116,6 +159,32 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
     DMA16((uint32_t)(g0__ * ld + vc0) * 2u, vbase, dv__);                                                        \
     if (DPW == 2) DMA16((uint32_t)(g1__ * ld + vc1) * 2u, vbase, dv__ + 1024);                                   \
   } while (0)
+  // full items: tile kt_ = keys 64 kt_ .. 64 kt_ + 63 in tile-row order.  The tile is a SCALAR base (kt_ is a loop counter on the
+  // scalar unit), the lane's share of it the constant offsets dK0 .. dV1: nothing is computed on the vector unit per tile, except
+  // in the last tile of a sequence whose rows past the end are clamped (wave-uniform branch).
+  const uint32_t dK0 = (uint32_t)(drow0 * ld + kc0) * 2u, dK1 = (uint32_t)(drow1 * ld + kc1) * 2u;
+  const uint32_t dV0 = (uint32_t)(drow0 * ld + vc0) * 2u, dV1 = (uint32_t)(drow1 * ld + vc1) * 2u;
+#define DMA_TILE(kt_, buf_)                                                                                      \
+  do {                                                                                                           \
+    const int key0__ = (kt_) * KB;                                                                               \
+    const bf16_t* kb__ = kbase + (size_t)key0__ * ld;                                                            \
+    const bf16_t* vb__ = vbase + (size_t)key0__ * ld;                                                            \
+    const uint32_t dk__ = kl_lds + (buf_) * (KB * 128) + wave_s * (1024 * DPW);                                  \
+    const uint32_t dv__ = vl_lds + (buf_) * (KB * 128) + wave_s * (1024 * DPW);                                  \
+    if (key0__ + KB <= S) {                                                                                      \
+      DMA16(dK0, kb__, dk__);                                                                                    \
+      if (DPW == 2) DMA16(dK1, kb__, dk__ + 1024);                                                               \
+      DMA16(dV0, vb__, dv__);                                                                                    \
+      if (DPW == 2) DMA16(dV1, vb__, dv__ + 1024);                                                               \
+    } else {                                                                                                     \
+      const int lim__ = S - 1 - key0__;                                                                          \
+      const int g0__ = drow0 < lim__ ? drow0 : lim__, g1__ = drow1 < lim__ ? drow1 : lim__;                      \
+      DMA16((uint32_t)(g0__ * ld + kc0) * 2u, kb__, dk__);                                                       \
+      if (DPW == 2) DMA16((uint32_t)(g1__ * ld + kc1) * 2u, kb__, dk__ + 1024);                                  \
+      DMA16((uint32_t)(g0__ * ld + vc0) * 2u, vb__, dv__);                                                       \
+      if (DPW == 2) DMA16((uint32_t)(g1__ * ld + vc1) * 2u, vb__, dv__ + 1024);                                  \
+    }                                                                                                            \
+  } while (0)
 
   f32x16 o_acc[2];
 #pragma unroll
@@ -145,14 +214,25 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 
   const int nkt = (S + KB - 1) / KB;
   if (mode == 0) {
-  f32x16 negm = zero16;            // PRE: start vector of the score accumulators = -m_run per lane (query)
-  if (PRE) m_run = 0.f;            // placeholder until the first tile sets the maximum
-  DMA2(0, 32, 0);
+  // PRE: start vectors of the two score accumulators = -m_run per lane (query); one per chain, so that neither MFMA chain has
+  // to copy its start vector into its accumulator first
+  f32x16 negm0 = zero16;
+  // third O^T tile: its V^T operand is the constant row A[0][k] = 1 (lanes 0 and 32), so its row 0 accumulates the row sums
+  constexpr bool MSUM = NE == 1;   // the 8-wave paired kernel is held to 128 registers: it keeps the vector-unit row sums
+  f32x16 o_sum = zero16;
+  const bf16_t one_or_zero = (bf16_t)(r == 0 ? 1.0f : 0.0f);
+  const bf16x8 ones_frag = {one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero};
+  if (PRE) m_run = 0.f;            // placeholder until the first tile sets the reference
+  DMA_TILE(0, 0);
+  STAMP_DECL;
+  STAMP_START();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile kt has landed
+    STAMP(0);                             // segment 0: wait for this wave's own DMA
     __syncthreads();                      // tile complete; every wave is done with the other stage
-    if (kt + 1 < nkt) DMA2((kt + 1) * KB, (kt + 1) * KB + 32, buf ^ 1);
+    STAMP(1);                             // segment 1: barrier
+    if (kt + 1 < nkt) DMA_TILE(kt + 1, buf ^ 1);
     const char* kt_lds = kbase_lds + buf * (KB * 128);
     const char* vt_lds = vbase_lds + buf * (KB * 128);
 
@@ -170,15 +250,27 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
         kf[t][3] = *reinterpret_cast<const bf16x8*>(kt_lds + koff3 + t * 4096);
       }
       // the two score tiles interleaved: consecutive MFMAs are independent, each chain of 4 has a tile's worth of slack
+      if (PRE) {
+        // both chains start from the same -m vector and must leave it intact: written as asm with early-clobber outputs, so the
+        // destination is a fresh register range (the builtin form makes hipcc copy the 16 registers and accumulate in place).
+        // Operands come from LDS reads (waited for by the compiler) or are long-lived: no VALU-write hazard ahead of them;
+        // the consumers are the next MFMAs of the same chain (accumulate dependency, interlocked in hardware).
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s_acc[0]) : "v"(kf[0][0]), "v"(qf[0]), "v"(negm0));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s_acc[1]) : "v"(kf[1][0]), "v"(qf[0]), "v"(negm0));
+      } else {
+        s_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][0], qf[0], zero16, 0, 0, 0);
+        s_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][0], qf[0], zero16, 0, 0, 0);
+      }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], ks ? s_acc[t] : (PRE ? negm : zero16), 0, 0, 0);
+          s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], s_acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, PRE ? 6 : 8, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    STAMP(2);                             // segment 2: DMA issue, K fragment reads, S MFMA issue
     // mask keys past the end of the sequence (last tile only)
     if (kt * KB + KB > S) {
 #pragma unroll
@@ -196,13 +288,20 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s_acc[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float psum = 0.f;
+#ifdef ATTN_STAMPS
+    asm volatile("" ::"v"(mx));
+#endif
+    STAMP(3);                             // segment 3: S MFMA completion, row maximum, lane exchange
     if (PRE) {
-      // the tile's scores are relative to the running maximum (they started from -m_run): a positive one raises it
-      if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0ull) {
+      // the tile's scores are relative to the running reference m_run (they started from -m_run).  The reference only has to keep
+      // exp2(score - m_run) in range, it need not be the exact maximum: it is moved up only when some score of the tile exceeds it
+      // by more than defer_thr (p <= 2^thr; bf16 P keeps its 8 significant bits at any magnitude, sums are fp32).  With the
+      // exact maximum as reference, one of a wave's 32 queries meets a new maximum in most tiles (1 - (1 - 1/(kt+1))^32) and the
+      // whole wave pays the 80-instruction shift of scores, sums and accumulators nearly every tile.
+      if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0ull) {
         const float d = kt == 0 ? mx - m_run : fmaxf(mx, 0.f);      // first tile: m_run is the placeholder 0
         const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-d);   // nothing accumulated yet on the first tile
-        l_run *= alpha;
+        if (MSUM) o_sum[0] *= alpha; else l_run *= alpha;           // rows 1.. of the third tile are zero
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -213,37 +312,38 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
           for (int e = 0; e < 16; ++e) s_acc[t][e] -= d;
         m_run += d;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) negm[e] = -m_run;
+        for (int e = 0; e < 16; ++e) negm0[e] = -m_run;
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          s_acc[t][e] = __builtin_amdgcn_exp2f(s_acc[t][e]);
-          psum += s_acc[t][e];
-        }
+        for (int e = 0; e < 16; ++e) s_acc[t][e] = __builtin_amdgcn_exp2f(s_acc[t][e]);
     } else {
-    const float m_new = fmaxf(m_run, mx);
-    const float mc = m_new * c_exp;
+      const float m_new = (mx - m_run) * c_exp > defer_thr ? mx : m_run;   // deferred reference (see the PRE branch); the -inf start moves
+      const float mc = m_new * c_exp;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        s_acc[t][e] = __builtin_amdgcn_exp2f(fmaf(s_acc[t][e], c_exp, -mc));
-        psum += s_acc[t][e];
+        for (int e = 0; e < 16; ++e) s_acc[t][e] = __builtin_amdgcn_exp2f(fmaf(s_acc[t][e], c_exp, -mc));
+      // rescale the running state only when some row's reference moved (wave-uniform branch; exact: alpha == 1 otherwise)
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+        if (MSUM) o_sum[0] *= alpha; else l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+        m_run = m_new;
       }
-    // rescale the running state only when some row's max moved (wave-uniform branch; exact: alpha == 1 otherwise)
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
-      m_run = m_new;
     }
+    if (!MSUM) {
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) psum += s_acc[t][e];
+      l_run += psum;
     }
-    l_run += psum;
     // P as bf16 B-operand fragments: k-step (t, sp) = registers 8sp..8sp+7 of score tile t
 #define PFRAG(t_, sp_)                                                                                             \
   ((bf16x8){(bf16_t)s_acc[t_][8 * sp_ + 0], (bf16_t)s_acc[t_][8 * sp_ + 1], (bf16_t)s_acc[t_][8 * sp_ + 2],        \
@@ -251,8 +351,12 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
             (bf16_t)s_acc[t_][8 * sp_ + 6], (bf16_t)s_acc[t_][8 * sp_ + 7]})
     const bf16x8 pf00 = PFRAG(0, 0), pf01 = PFRAG(0, 1), pf10 = PFRAG(1, 0), pf11 = PFRAG(1, 1);
 #undef PFRAG
+#ifdef ATTN_STAMPS
+    asm volatile("" ::"v"(pf00), "v"(pf01), "v"(pf10), "v"(pf11));
+#endif
+    STAMP(4);                             // segment 4: exp2, bf16 pack
 
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V^T P^T, row sums += 1^T P^T ----
     // the V^T fragments of a d-half are requested together, one half ahead of the MFMAs that use them
 #define VFRAG(dt_, t_, sp_)                                                                                        \
   ({                                                                                                               \
@@ -264,21 +368,35 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
       bf16x8 vf0[4], vf1[4];
       vf0[0] = VFRAG(0, 0, 0); vf0[1] = VFRAG(0, 0, 1); vf0[2] = VFRAG(0, 1, 0); vf0[3] = VFRAG(0, 1, 1);
       vf1[0] = VFRAG(1, 0, 0); vf1[1] = VFRAG(1, 0, 1); vf1[2] = VFRAG(1, 1, 0); vf1[3] = VFRAG(1, 1, 1);
+      if (MSUM) o_sum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pf00, o_sum, 0, 0, 0);
       o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[0], pf00, o_acc[0], 0, 0, 0);
       o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[0], pf00, o_acc[1], 0, 0, 0);
+      if (MSUM) o_sum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pf01, o_sum, 0, 0, 0);
       o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[1], pf01, o_acc[0], 0, 0, 0);
       o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[1], pf01, o_acc[1], 0, 0, 0);
+      if (MSUM) o_sum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pf10, o_sum, 0, 0, 0);
       o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[2], pf10, o_acc[0], 0, 0, 0);
       o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[2], pf10, o_acc[1], 0, 0, 0);
+      if (MSUM) o_sum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, pf11, o_sum, 0, 0, 0);
       o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[3], pf11, o_acc[0], 0, 0, 0);
       o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[3], pf11, o_acc[1], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MSUM ? 12 : 8, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef VFRAG
+    STAMP(5);                             // segment 5: V fragment reads, PV MFMA issue
 
   }
+#ifdef ATTN_STAMPS
+  if (stamps && blockIdx.x % 37 == 0 && lane == 0) {
+    long long* dst = stamps + ((size_t)(blockIdx.x / 37) * 4 + wave) * 8;
+    for (int i = 0; i < 6; ++i) dst[i] = (long long)st_acc__[i];
+    dst[6] = nkt;
+    dst[7] = (long long)st_prev__;
+  }
+#endif
+  if (MSUM) l_run = o_sum[0];      // row 0 of the third tile (lanes 0..31); lanes 32..63 hold its row 4 = 0
   } else {
     // ================= half item: 64 queries, the key range split between the two wave pairs =================
     const int kh = __builtin_amdgcn_readfirstlane(wave >> 1);
@@ -315,7 +433,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
+        const float m_new = (mx - m_run) * c_exp > defer_thr ? mx : m_run;
         const float mc = m_new * c_exp;
         float psum = 0.f;
 #pragma unroll
@@ -386,116 +504,220 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 2) void k_attn_bf16(const b
     }
   }
 #undef DMA2
+#undef DMA_TILE
 #undef DMA16
 
   // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv_l = 1.0f / l_tot;
+  const float inv_l = __builtin_amdgcn_rcpf(l_tot);
   if (!live) return;
-  if (lse_out && qrow < S && h == 0)   // natural-log LSE of the scaled scores (training tape): scale*max + ln(sum)
+  if (TAPE && lse_out && qrow < S && h == 0)   // natural-log LSE of the scaled scores (training tape): scale*max + ln(sum)
     lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run * (c_exp * 0.69314718055994530942f) + __logf(l_tot);
-  if (qrow < S) {
-    bf16_t* orow = out + (size_t)(s0 + qrow) * ldo + head * 64;
-    const bf16_t* grow = gbase + (size_t)qrow * ld;
+  {
+    // Every lane computes (rows past the end are clamped for the gate load), lanes exchange, rows < S store.  Lanes (r, 0) and
+    // (r, 1) hold the 4-feature groups 8g + 0..3 and 8g + 4..7 of a row: for each pair of groups (g, g + 1) one
+    // v_permlane32_swap per dword leaves lane (r, 0) with features 8g .. 8g + 7 and lane (r, 1) with 8(g+1) .. 8(g+1) + 7:
+    // one 16-byte store per lane and pair instead of two 8-byte ones.
+    bf16_t* orow = out + (size_t)(s0 + qrc) * ldo + head * 64;
+    const bf16_t* grow = gbase + (size_t)qrc * ld;
+    const bool store = qrow < S;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = dt * 32 + 8 * g + 4 * h;
-        f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
-        if (out_raw) {   // training tape: the ungated output as well; the gate then multiplies the stored (rounded) value
-          Vec4<bf16_t>::store(out_raw + (size_t)(s0 + qrow) * ldo + head * 64 + d0, v);
+      for (int gp = 0; gp < 2; ++gp) {
+        uint2 pk[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = round_to<bf16_t>(v[e]);
-        }
-        if (GATE) {
-          const f32x4 gt = Vec4<bf16_t>::load(grow + d0);
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * gp + gg;
+          const int d0 = dt * 32 + 8 * g + 4 * h;
+          f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+          if (TAPE && out_raw) {   // training tape: the ungated output as well; the gate then multiplies the stored (rounded) value
+            if (store) Vec4<bf16_t>::store(out_raw + (size_t)(s0 + qrow) * ldo + head * 64 + d0, v);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= 1.0f / (1.0f + __expf(-gt[e]));
+            for (int e = 0; e < 4; ++e) v[e] = round_to<bf16_t>(v[e]);
+          }
+          if (GATE) {
+            const f32x4 gt = Vec4<bf16_t>::load(grow + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gt[e] * -1.44269504088896340736f));
+          }
+          const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          pk[gg] = __builtin_bit_cast(uint2, b4);
         }
-        Vec4<bf16_t>::store(orow + d0, v);
+        // lanes 32..63 of pk[0] <-> lanes 0..31 of pk[1]
+        const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        // lane (r,0): [own group 2gp | partner's group 2gp] = features 16gp .. 16gp + 7 of the d-half;
+        // lane (r,1): [partner's group 2gp+1 | own group 2gp+1] = features 16gp + 8 .. 16gp + 15
+        const uint4 o16 = {sx[0], sy[0], sx[1], sy[1]};
+        if (store) *reinterpret_cast<uint4*>(orow + dt * 32 + 16 * gp + 8 * h) = o16;
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32 parity kernel: block = 4 waves, 128 queries; wave w walks queries w*32..w*32+31 one at a time,
-// lane j scores key j of the current 64-key tile, lane d accumulates output dim d.
+// fp32 kernel: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate = an fmaf chain per output; 157 TFLOP/s peak).
+// The compute path of `dtype=float32` towers - the mode whose token indices equal the reference's fp32 result.
+// Same decomposition as the bf16 kernel: block = 4 waves = 128 query rows of one (sequence, q-head), 32 queries per wave,
+// 64-key K / V tiles in LDS (register-staged, the next tile's loads in flight behind the MFMAs of the current one).
+//   S^T = K Q^T   : key on the MFMA row, query on the lane.  One MFMA sums 2 head dims: lane half h supplies dims 32h + i at
+//                   step i (Q: 32 registers per lane, loaded once; K: ds_read_b128 of the lane's key row, 16-byte chunks
+//                   XOR-swizzled by key & 15 so that the 16 lanes of a read group hit 16 different slots).
+//   O^T = V^T P^T : the S^T accumulator registers ARE the B operand, unconverted: register e of lane half h is key
+//                   (e & 3) + 8 (e >> 2) + 4h of the 32-key sub-tile, so step e sums keys k_e(0), k_e(1) and the A operand is
+//                   V[k_e(h)][d = lane & 31 (+32)], a plain ds_read_b32 of the row-major V tile (conflict-free: 32 consecutive
+//                   floats per half).
+// Softmax in fp32 with exp2 (scale * log2 e folded into one FMA); rescale only when a row maximum moved.
+// Half items (mode 1) are computed as 64-query items by waves 0,1 over the whole key range (same arithmetic as a full item).
 // ------------------------------------------------------------------------------------------------
 template <bool GATE>
-__global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
-                                                  const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
-                                                  int rep, float scale, float* __restrict__ lse_out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* qs = smem;                    // [128][64]
-  float* ks = qs + QB * 64;            // [64][65]
-  float* vs = ks + KB * 65;            // [64][64]
-  float* ps = vs + KB * 64;            // [4][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256, 2) void k_attn_f32(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
+                                                     const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
+                                                     int rep, float c_exp /* scale * log2(e) */, float* __restrict__ lse_out) {
+  __shared__ __attribute__((aligned(16))) uint4 kl[KB * 16];   // [key][16 chunks of 4 floats], chunk c at c ^ (key & 15)
+  __shared__ __attribute__((aligned(16))) float vl[KB * 64];   // [key][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
   const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
+  const int mode = qblocks[4 * blockIdx.x + 3];
   if (seq < 0) return;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
-  const int q_lim = (qblocks[4 * blockIdx.x + 3] && q0 + 64 < S) ? q0 + 64 : S;   // half item: 64 query rows (see the bf16 kernel)
+  const int q_lim = (mode && q0 + 64 < S) ? q0 + 64 : S;      // half item: 64 query rows
+  const bool wave_live = !(mode && wave >= 2);                 // its waves 2,3 only help staging
   const int kvh = head / rep;
   const float* qbase = qkvg + (size_t)s0 * ld + head * 64;
   const float* gbase = qkvg + (size_t)s0 * ld + d_model + head * 64;
   const float* kbase = qkvg + (size_t)s0 * ld + 2 * d_model + kvh * 64;
   const float* vbase = kbase + gqa;
 
-  for (int i = tid; i < QB * 64; i += 256) {
-    int row = q0 + (i >> 6);
-    row = row < S ? row : S - 1;
-    qs[i] = qbase[(size_t)row * ld + (i & 63)];
-  }
-  float m_run[32], l_run[32], o[32];
+  // Q fragments: lane holds Q[query r][32h + 0..31]
+  const int qrow = q0 + wave * 32 + r;
+  const int qrc = qrow < S ? qrow : S - 1;
+  f32x4 qf[8];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) { m_run[i] = -INFINITY; l_run[i] = 0.f; o[i] = 0.f; }
+  for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4*>(qbase + (size_t)qrc * ld + h * 32 + c * 4);
+
+  // staging: a K / V tile is 64 keys x 16 chunks; thread t takes chunk t & 15 of keys (t >> 4) + 16 i
+  const int skey = tid >> 4, sch = tid & 15;
+  uint4 sk0, sk1, sk2, sk3, sv0, sv1, sv2, sv3;
+#define A32_GLOAD(kt_)                                                                     \
+  do {                                                                                     \
+    int k0__ = (kt_) * KB + skey, k1__ = k0__ + 16, k2__ = k0__ + 32, k3__ = k0__ + 48;    \
+    k0__ = k0__ < S ? k0__ : S - 1; k1__ = k1__ < S ? k1__ : S - 1;                        \
+    k2__ = k2__ < S ? k2__ : S - 1; k3__ = k3__ < S ? k3__ : S - 1;                        \
+    sk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)k0__ * ld + sch * 4);            \
+    sk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)k1__ * ld + sch * 4);            \
+    sk2 = *reinterpret_cast<const uint4*>(kbase + (size_t)k2__ * ld + sch * 4);            \
+    sk3 = *reinterpret_cast<const uint4*>(kbase + (size_t)k3__ * ld + sch * 4);            \
+    sv0 = *reinterpret_cast<const uint4*>(vbase + (size_t)k0__ * ld + sch * 4);            \
+    sv1 = *reinterpret_cast<const uint4*>(vbase + (size_t)k1__ * ld + sch * 4);            \
+    sv2 = *reinterpret_cast<const uint4*>(vbase + (size_t)k2__ * ld + sch * 4);            \
+    sv3 = *reinterpret_cast<const uint4*>(vbase + (size_t)k3__ * ld + sch * 4);            \
+  } while (0)
+  // (skey + 16 i) & 15 == skey: one swizzled chunk position for the four rows
+  const int kli = skey * 16 + (sch ^ skey);
+  uint4* vl4 = reinterpret_cast<uint4*>(vl);
+#define A32_LSTORE()                                                                       \
+  do {                                                                                     \
+    kl[kli] = sk0; kl[kli + 256] = sk1; kl[kli + 512] = sk2; kl[kli + 768] = sk3;          \
+    vl4[tid] = sv0; vl4[tid + 256] = sv1; vl4[tid + 512] = sv2; vl4[tid + 768] = sv3;      \
+  } while (0)
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
+  A32_GLOAD(0);
   for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();            // every wave is done with the previous tile
+    A32_LSTORE();
     __syncthreads();
-    for (int i = tid; i < KB * 64; i += 256) {
-      int key = kt * KB + (i >> 6);
-      key = key < S ? key : S - 1;
-      ks[(i >> 6) * 65 + (i & 63)] = kbase[(size_t)key * ld + (i & 63)];
-      vs[i] = vbase[(size_t)key * ld + (i & 63)];
-    }
-    __syncthreads();
-    const bool valid = (kt * KB + lane) < S;
+    if (kt + 1 < nkt) A32_GLOAD(kt + 1);   // in flight behind this tile's MFMAs
+    if (wave_live) {
 #pragma unroll
-    for (int qi = 0; qi < 32; ++qi) {
-      const float* qv = qs + (wave * 32 + qi) * 64;
-      float sdot = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < 64; ++d) sdot = fmaf(qv[d], ks[lane * 65 + d], sdot);
-      sdot = valid ? sdot * scale : -INFINITY;
-      const float mx = wave_max(sdot);
-      const float m_new = fmaxf(m_run[qi], mx);
-      const float alpha = expf(m_run[qi] - m_new);
-      const float pj = expf(sdot - m_new);
-      l_run[qi] = l_run[qi] * alpha + wave_sum(pj);
-      m_run[qi] = m_new;
-      ps[wave * 64 + lane] = pj;
-      __builtin_amdgcn_wave_barrier();
-      float acc = o[qi] * alpha;
-#pragma unroll 16
-      for (int j = 0; j < 64; ++j) acc = fmaf(ps[wave * 64 + j], vs[j * 64 + lane], acc);
-      o[qi] = acc;
-      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < 2; ++t) {        // two 32-key sub-tiles
+        if (kt * KB + t * 32 >= S) break;  // wave-uniform
+        // ---- S^T = K Q^T ----
+        f32x16 sc = zero16;
+        const int key = t * 32 + r;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const f32x4 kf = __builtin_bit_cast(f32x4, kl[key * 16 + ((h * 8 + c) ^ (key & 15))]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], sc, 0, 0, 0);
+        }
+        if (kt * KB + t * 32 + 32 > S) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int kk = kt * KB + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (kk >= S) sc[e] = -INFINITY;
+          }
+        }
+        // ---- online softmax ----
+        float mx = sc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mc = m_new * c_exp;
+        float psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          sc[e] = __builtin_amdgcn_exp2f(fmaf(sc[e], c_exp, -mc));
+          psum += sc[e];
+        }
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+          l_run *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+          m_run = m_new;
+        }
+        l_run += psum;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int vk = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v0 = vl[vk * 64 + r], v1 = vl[vk * 64 + 32 + r];
+          o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[e], o_acc[0], 0, 0, 0);
+          o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[e], o_acc[1], 0, 0, 0);
+        }
+      }
     }
   }
+#undef A32_GLOAD
+#undef A32_LSTORE
+  if (!wave_live) return;
+
+  // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (lse_out && qrow < q_lim && h == 0)
+    lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run * (c_exp * 0.69314718055994530942f) + logf(l_tot);
+  if (qrow < q_lim) {
+    float* orow = out + (size_t)(s0 + qrow) * ldo + head * 64;
+    const float* grow = gbase + (size_t)qrow * ld;
 #pragma unroll
-  for (int qi = 0; qi < 32; ++qi) {
-    const int qrow = q0 + wave * 32 + qi;
-    if (lse_out && qrow < q_lim && lane == 0) lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run[qi] + logf(l_run[qi]);
-    if (qrow < q_lim) {
-      float v = o[qi] / l_run[qi];
-      if (GATE) {
-        const float g = gbase[(size_t)qrow * ld + lane];
-        v *= 1.0f / (1.0f + expf(-g));
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+        if (GATE) {
+          const f32x4 gt = *reinterpret_cast<const f32x4*>(grow + d0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= 1.0f / (1.0f + expf(-gt[e]));
+        }
+        *reinterpret_cast<f32x4*>(orow + d0) = v;
       }
-      out[(size_t)(s0 + qrow) * ldo + head * 64 + lane] = v;
-    }
   }
 }
 
@@ -511,7 +733,7 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention: q_heads %% kv_heads");
   const int d_model = q_heads * 64, gqa = kv_heads * 64, rep = q_heads / kv_heads;
   TTV_CHECK_ARG(ld >= 2 * d_model + 2 * gqa && ld % 8 == 0 && ldo % 4 == 0, "attention: bad leading dims");
-  TTV_CHECK_ARG((uintptr_t)qkvg % 16 == 0 && (uintptr_t)out % 8 == 0, "attention: unaligned pointers");
+  TTV_CHECK_ARG((uintptr_t)qkvg % 16 == 0 && (uintptr_t)out % (dtype == TTV_F32 ? 16 : 8) == 0, "attention: unaligned pointers");
   dim3 grid(n_qblocks);   // one entry per (sequence, 128-query block, q-head), XCD-interleaved by the host
   const float scale = 0.125f;  // 64^-0.5
   TtvProfScope prof(TTV_KC_ATTENTION, s);
@@ -520,14 +742,18 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
     // pre-scaled q: the exponent factor is 1; the accumulator-carried maximum (PRE) is built for the 4-wave kernel only - the paired
     // kernel is held to 128 VGPRs and would spill its start vector - so paired launches run the generic softmax with factor 1
     const float c_eff = prescaled ? 1.0f : c_exp;
-#define ATTN_LAUNCH(G_, NE_, P_, grid_, threads_)                                                                                   \
-  hipLaunchKernelGGL((k_attn_bf16<G_, NE_, (P_) && (NE_) == 1>), grid_, dim3(threads_), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, \
-                     cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_eff, lse_out, (bf16_t*)out_raw)
+    static const float defer_thr = getenv("TTV_ATTN_THR") ? (float)atof(getenv("TTV_ATTN_THR")) : ATTN_DEFER_THR;   // diagnostics: 0 = exact running maximum
+#define ATTN_LAUNCH(G_, NE_, P_, T_, grid_, threads_)                                                                                   \
+  hipLaunchKernelGGL((k_attn_bf16<G_, NE_, (P_) && (NE_) == 1, T_>), grid_, dim3(threads_), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, \
+                     cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, c_eff, lse_out, (bf16_t*)out_raw, defer_thr, g_ttv_stamps)
 #define ATTN_PICK(NE_, grid_, threads_)                                                  \
   do {                                                                                   \
-    if (gate_mul) { if (prescaled) ATTN_LAUNCH(true, NE_, true, grid_, threads_); else ATTN_LAUNCH(true, NE_, false, grid_, threads_); }   \
-    else { if (prescaled) ATTN_LAUNCH(false, NE_, true, grid_, threads_); else ATTN_LAUNCH(false, NE_, false, grid_, threads_); }          \
+    if (tape) { if (gate_mul) ATTN_LAUNCH(true, NE_, false, true, grid_, threads_); else ATTN_LAUNCH(false, NE_, false, true, grid_, threads_); }  \
+    else if (gate_mul) { if (prescaled) ATTN_LAUNCH(true, NE_, true, false, grid_, threads_); else ATTN_LAUNCH(true, NE_, false, false, grid_, threads_); }   \
+    else { if (prescaled) ATTN_LAUNCH(false, NE_, true, false, grid_, threads_); else ATTN_LAUNCH(false, NE_, false, false, grid_, threads_); }          \
   } while (0)
+    const bool tape = lse_out != nullptr || out_raw != nullptr;
+    TTV_CHECK_ARG(!tape || !prescaled, "attention: the training-tape outputs need unscaled q");
     if (paired) {
       // rows of 8 list slots; a block takes two consecutive rows of one slot
       const int rows = ttv_cdiv(n_qblocks, 8), pairs = ttv_cdiv(rows, 2);
@@ -539,14 +765,11 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
 #undef ATTN_PICK
 #undef ATTN_LAUNCH
   } else if (dtype == TTV_F32) {
-    const size_t smem = (QB * 64 + KB * 65 + KB * 64 + 4 * 64) * sizeof(float);
-    if (gate_mul) {
-      (void)hipFuncSetAttribute((const void*)k_attn_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale, lse_out);
-    } else {
-      (void)hipFuncSetAttribute((const void*)k_attn_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL((k_attn_f32<false>), grid, dim3(256), smem, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, scale, lse_out);
-    }
+    const float c_exp = scale * 1.44269504088896340736f;
+    if (gate_mul)
+      hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
+    else
+      hipLaunchKernelGGL((k_attn_f32<false>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
   } else {
     ttv_set_error("attention: bad dtype");
     return TTV_ERR_INVALID;

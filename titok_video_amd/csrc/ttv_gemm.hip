@@ -19,7 +19,7 @@
 //                 (token tile, panel) items, and the preceding RMSNorm is folded in (PRENORM).
 //   k_gemm_bf16 : general K: 128 features x 128 tokens x 64 K tiles, 4 waves (2x2), register-staged double-buffered
 //                 LDS, XOR-swizzled 16-byte chunks (conflict-free ds_read_b128), XCD-aware tile order.
-//   k_gemm_f32  : parity instrument only (the reference never runs fp32 on GPU): 64x64x16 tiles, VALU FMAs.
+//   k_gemm_f32  : fp32 towers (bit-exact token indices): exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), 128x128x32 tiles.
 #include "ttv_common.h"
 #include "ttv_kernels.h"
 
@@ -845,68 +845,136 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
 }
 
 // ================================================================================================
-// fp32 kernel (parity instrument)
+// fp32 kernel: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate, one rounding per product = an fmaf chain;
+// 64 FLOP/clk/SIMD = the fp32 vector peak, 157 TFLOP/s on MI355X).  This is the compute path of `dtype=float32` towers, the
+// mode in which token indices equal the reference's fp32 result (fsq.py:123-135 rounds after tanh: bf16 cannot be bit-exact).
+// Same orientation and C layout as the bf16 kernel (a lane owns 4 consecutive output features of one token), so the epilogues
+// are shared.  128 features x 128 tokens x 32 K per step, 4 waves (2 x 2), register-staged double-buffered LDS; rows are 128
+// bytes = 8 chunks of 16 bytes, chunk kc of row r stored at kc ^ (r & 7) (conflict-free ds_read_b128 for the lane -> (row, kq)
+// fragment pattern, contiguous ds_write_b128).  A lane's 16-byte chunk holds k = 4 kq .. 4 kq + 3 of a 16-k block: MFMA step jj
+// of the block therefore sums k in {jj, 4 + jj, 8 + jj, 12 + jj} - a fixed permutation of the summation order, the same
+// for both operands.
 // ================================================================================================
-#define F_TF 64
-#define F_TT 64
-#define F_BK 16
+#define F_TF 128
+#define F_TT 128
+#define F_BK 32
 
 template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmDev p, int n_ftiles) {
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
-  __shared__ float ws[F_BK][F_TF + 4];
-  __shared__ float ws2[DUAL ? F_BK : 1][F_TF + 4];
-  __shared__ float xs[F_BK][F_TT + 4];
-  const int tid = threadIdx.x;
-  const int fbase = (blockIdx.x % n_ftiles) * F_TF;
-  const int tbase = (blockIdx.x / n_ftiles) * F_TT;
+  constexpr int FT = DUAL ? 64 : F_TF;
+  __shared__ uint4 lds[2][(F_TF + F_TT) * 8];   // [buffer][w rows 0..127 | x rows 0..127][row*8 + swizzled chunk], 2 x 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wf = wave & 1, wt = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int fbase = (tile % n_ftiles) * FT;
+  const int tbase = (tile / n_ftiles) * F_TT;
   const float* W = (const float*)p.w;
   const float* X = (const float*)p.x;
-  const int lrow = tid >> 2, lk = (tid & 3) * 4;
-  int wr = fbase + lrow; wr = wr < p.N ? wr : p.N - 1;
-  int xr = tbase + lrow; xr = xr < p.M ? xr : p.M - 1;
-  const int tf = tid & 15, tt = tid >> 4;
-  float acc[4][4] = {}, acc2[4][4] = {};
-  for (int k0 = 0; k0 < p.K; k0 += F_BK) {
-    const bool ok = (k0 + lk) < p.K;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 vw = ok ? *reinterpret_cast<const f32x4*>(W + (size_t)wr * p.ldw + k0 + lk) : zero;
-    const f32x4 vx = ok ? *reinterpret_cast<const f32x4*>(X + (size_t)xr * p.ldx + k0 + lk) : zero;
-    f32x4 vw2 = zero;
-    if (DUAL) vw2 = ok ? *reinterpret_cast<const f32x4*>(W + (size_t)(p.N + wr) * p.ldw + k0 + lk) : zero;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ws[lk + e][lrow] = vw[e];
-      xs[lk + e][lrow] = vx[e];
-      if (DUAL) ws2[lk + e][lrow] = vw2[e];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < F_BK; ++k) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&ws[k][tf * 4]);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(&xs[k][tt * 4]);
-      f32x4 a2 = a;
-      if (DUAL) a2 = *reinterpret_cast<const f32x4*>(&ws2[k][tf * 4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-          if (DUAL) acc2[i][j] = fmaf(a2[i], b[j], acc2[i][j]);
-        }
-    }
+
+  // staging: 1024 chunks per operand and k-step, 4 per thread: row = (tid >> 3) + 32 i, chunk kc = tid & 7
+  const int srow = tid >> 3, skc = tid & 7;
+  const float* wp0; const float* wp1; const float* wp2; const float* wp3;
+  const float* xp0; const float* xp1; const float* xp2; const float* xp3;
+  {
+    auto wrow = [&](int row) {
+      int wr;
+      if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
+      else wr = fbase + row;
+      wr = wr < p.w_rows ? wr : p.w_rows - 1;
+      return W + (size_t)wr * p.ldw + skc * 4;
+    };
+    auto xrow = [&](int row) {
+      int xr = tbase + row;
+      xr = xr < p.M ? xr : p.M - 1;
+      return X + (size_t)xr * p.ldx + skc * 4;
+    };
+    wp0 = wrow(srow); wp1 = wrow(srow + 32); wp2 = wrow(srow + 64); wp3 = wrow(srow + 96);
+    xp0 = xrow(srow); xp1 = xrow(srow + 32); xp2 = xrow(srow + 64); xp3 = xrow(srow + 96);
   }
-  // one "m-tile" of 4 consecutive features, 4 "n-tiles" of one token each
-  int tok[4], feat[1] = {fbase + tf * 4};
-  f32x4 v[1][4], v2[1][4];
+  const int li0 = srow * 8 + (skc ^ (srow & 7));            // (srow + 32 i) & 7 == srow & 7
+  const int li1 = li0 + 32 * 8, li2 = li0 + 64 * 8, li3 = li0 + 96 * 8;
+
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    tok[j] = tbase + tt * 4 + j;
-    v[0][j] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-    v2[0][j] = (f32x4){acc2[0][j], acc2[1][j], acc2[2][j], acc2[3][j]};
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 sw0, sw1, sw2, sw3, sx0, sx1, sx2, sx3;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+#define FGLOAD(k0)                                                                  \
+  do {                                                                              \
+    const bool ok__ = ((k0) + skc * 4) < p.K;                                       \
+    sw0 = ok__ ? *reinterpret_cast<const uint4*>(wp0 + (k0)) : zero4;               \
+    sw1 = ok__ ? *reinterpret_cast<const uint4*>(wp1 + (k0)) : zero4;               \
+    sw2 = ok__ ? *reinterpret_cast<const uint4*>(wp2 + (k0)) : zero4;               \
+    sw3 = ok__ ? *reinterpret_cast<const uint4*>(wp3 + (k0)) : zero4;               \
+    sx0 = ok__ ? *reinterpret_cast<const uint4*>(xp0 + (k0)) : zero4;               \
+    sx1 = ok__ ? *reinterpret_cast<const uint4*>(xp1 + (k0)) : zero4;               \
+    sx2 = ok__ ? *reinterpret_cast<const uint4*>(xp2 + (k0)) : zero4;               \
+    sx3 = ok__ ? *reinterpret_cast<const uint4*>(xp3 + (k0)) : zero4;               \
+  } while (0)
+#define FLSTORE(buf)                                                                \
+  do {                                                                              \
+    lds[buf][li0] = sw0; lds[buf][li1] = sw1; lds[buf][li2] = sw2; lds[buf][li3] = sw3;                       \
+    lds[buf][F_TF * 8 + li0] = sx0; lds[buf][F_TF * 8 + li1] = sx1; lds[buf][F_TF * 8 + li2] = sx2; lds[buf][F_TF * 8 + li3] = sx3; \
+  } while (0)
+
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nk = (p.K + F_BK - 1) / F_BK;
+  FGLOAD(0);
+  FLSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) FGLOAD((kt + 1) * F_BK);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 a[4], b[4];
+      const int kc = kb * 4 + kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+        a[i] = __builtin_bit_cast(f32x4, lds[buf][arow * 8 + (kc ^ (arow & 7))]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int brow = wt * 64 + j * 16 + l15;
+        b[j] = __builtin_bit_cast(f32x4, lds[buf][F_TF * 8 + brow * 8 + (kc ^ (brow & 7))]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) FLSTORE(buf ^ 1);
+    __syncthreads();
   }
-  epilogue_tile<EPI, float, 1, 4>(p, tok, feat, v, v2, 0);
+#undef FGLOAD
+#undef FLSTORE
+
+  int tok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tok[j] = tbase + wt * 64 + j * 16 + l15;
+  if (DUAL) {
+    int feat[2];
+    f32x4 ax[2][4], ag[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
+    }
+    epilogue_tile<EPI, float, 2, 4>(p, tok, feat, ax, ag, kq);
+  } else {
+    int feat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
+    epilogue_tile<EPI, float, 4, 4>(p, tok, feat, acc, acc, kq);
+  }
 }
 
 template <int EPI>
@@ -936,7 +1004,7 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     else
       hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
   } else {
-    const int nf = ttv_cdiv(d.N, F_TF), nt = ttv_cdiv(d.M, F_TT);
+    const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT);
     hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
   }
   TTV_CHECK_LAUNCH("gemm");

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Where a wave of the bf16 attention kernel spends its cycles: per-segment s_memtime sums of the key loop (diagnostic build
+tools/attn_stamps.sh, loaded through TTV_LIB_PATH).  Shares are meaningful, the run time of this build is not.
+
+    bash tools/attn_stamps.sh && TTV_LIB_PATH=titok_video_amd/csrc/build/libtitok_hip_stamps.so python3 tools/attn_stamps.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from titok_video_amd import _lib  # noqa: E402
+from titok_video_amd.plan import BatchPlan  # noqa: E402
+
+DEV = torch.device("cuda:0")
+lib = _lib.lib()
+ST = _lib.stream_ptr(DEV)
+B = int(os.environ.get("B", "32"))
+plan = BatchPlan([(16, 128, 128)] * B, [128] * B, (4, 8, 8), DEV)
+L = plan.total_rows
+table = plan.attention_table(4, 2)
+qkv = (torch.randn(L, 768, device=DEV) * 0.9).to(torch.bfloat16)
+out = torch.empty(L, 256, dtype=torch.bfloat16, device=DEV)
+n_samples = (table.shape[0] + 36) // 37
+stamps = torch.zeros(n_samples * 4 * 8, dtype=torch.int64, device=DEV)
+lib.ttv_debug_stamps(stamps.data_ptr())
+for flags, name in ((1, "gate"), (1 | 4, "gate+qscaled")):
+    for _ in range(3):
+        _lib.check(lib.ttv_attention(qkv.data_ptr(), 768, out.data_ptr(), 256, plan.cu_dev.data_ptr(), table.data_ptr(), table.shape[0], 4, 2, 64, flags, 0, ST), "attn")
+    torch.cuda.synchronize()
+    s = stamps.view(n_samples, 4, 8).cpu().double()
+    seg = s[:, :, :6]
+    tiles = s[:, :, 6].clamp(min=1)
+    per_tile = (seg / tiles[..., None])
+    tot = per_tile.sum(-1)
+    names = ["own DMA wait", "barrier", "DMA issue+K reads+S mfma issue", "S done+max+exchange", "exp2+pack", "V reads+PV issue"]
+    print(f"---- {name}: {n_samples} sampled blocks x 4 waves; cycles per key tile (mean | min | max over sampled waves)")
+    for i, nm in enumerate(names):
+        v = per_tile[..., i]
+        print(f"  {nm:34s} {float(v.mean()):8.0f} | {float(v.min()):8.0f} | {float(v.max()):8.0f}   {100 * float((v / tot).mean()):5.1f} %")
+    print(f"  {'total per tile':34s} {float(tot.mean()):8.0f} | {float(tot.min()):8.0f} | {float(tot.max()):8.0f}")
+    first = tot[: n_samples // 2].mean()
+    last = tot[n_samples // 2:].mean()
+    print(f"  first half of the grid {float(first):.0f}, second half {float(last):.0f} cycles per tile")
+lib.ttv_debug_stamps(None)
