@@ -122,6 +122,16 @@ int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, 
                          const void* mlp_packed, int inner, void* y, int ldy, const float* ffd_post_gain, float ffd_alpha, float eps,
                          int M, int width, int dtype, const ttv_next_qkv* next, void* stream);
 
+/* Token / patch initialisation of the towers (blocks.py:95-97 encoder, :165-167 decoder), exported for parity tests:
+ * constant rows x[rows_map[i]] = RMSNorm(mask_token * 1_d) * gain - the encoder's latent rows (ln_pre_t) and the decoder's patch
+ * rows (ln_pre_p); */
+int ttv_fill_const_rows(void* x, int dtype, int ld, const int32_t* rows_map, int rows, int width, const float* mask_token,
+                        const float* gain, float eps, void* stream);
+/* the decoder's latent rows x[rows_map[i]] = RMSNorm(proj_in(codes[i]) + mask_token) * gain (blocks.py:125,165-166):
+ * codes [rows, token_size] (dtype), w [width, token_size], bias [width] (dtype). */
+int ttv_decoder_embed(const void* codes, int token_size, const void* w, const void* bias, const float* mask_token, const float* gain,
+                      void* x, int dtype, int ld, const int32_t* rows_map, int rows, int width, float eps, void* stream);
+
 /* flash_attn_varlen_func as called at transformer.py:100, fused with the sigmoid gate of transformer.py:103:
  * qkvg [L, 2d+2g] packed (q | gate | k | v) with RoPE already applied to q,k; out [L,d] = attn * sigmoid(gate).
  * Non-causal, block-diagonal over cu_seqlens (device int32 [n_seq+1]), GQA, softmax scale head_dim^-0.5.

@@ -130,19 +130,29 @@ def rmsnorm(x: Tensor, weight: Tensor, eps: float = RMS_EPS) -> Tensor:
 
 def attention_varlen(q: Tensor, k: Tensor, v: Tensor, cu_seqlens: Sequence[int]) -> Tensor:
     """flash_attn_varlen_func semantics at transformer.py:100: per-sequence, non-causal
-    softmax(q k^T / sqrt(D)) v, GQA (q head h uses kv head h // (Hq/Hkv)), fp32 math."""
+    softmax(q k^T / sqrt(D)) v, GQA (q head h uses kv head h // (Hq/Hkv)).
+
+    fp32 inputs: fp32 math throughout.  16-bit inputs (flash-attn only takes fp16 / bf16): the published
+    FlashAttention-2 arithmetic - scores and softmax statistics in fp32, the unnormalised probabilities exp(s - max) rounded
+    to the input dtype as the operand of the second product, fp32 accumulation, one division by the fp32 row sum at the end."""
     L, Hq, D = q.shape
     Hkv = k.shape[1]
     rep = Hq // Hkv
     out = torch.empty_like(q, dtype=torch.float32)
     scale = D ** -0.5
+    low = q.dtype in (torch.bfloat16, torch.float16)
     for b in range(len(cu_seqlens) - 1):
         s, e = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
         qb = q[s:e].float().transpose(0, 1)                       # [Hq, S, D]
         kb = k[s:e].float().transpose(0, 1).repeat_interleave(rep, dim=0)
         vb = v[s:e].float().transpose(0, 1).repeat_interleave(rep, dim=0)
-        p = torch.softmax(qb @ kb.transpose(1, 2) * scale, dim=-1)
-        out[s:e] = (p @ vb).transpose(0, 1)
+        sc = qb @ kb.transpose(1, 2) * scale
+        if low:
+            pt = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+            o = (pt.to(q.dtype).float() @ vb) / pt.sum(dim=-1, keepdim=True)
+        else:
+            o = torch.softmax(sc, dim=-1) @ vb
+        out[s:e] = o.transpose(0, 1)
     return out.to(q.dtype)
 
 

@@ -68,7 +68,13 @@ def test_fsq_kat_bit_exact(tag):
     margin = O.fsq_margin(ref_b).numpy()
     safe = margin > 4e-6
     assert np.array_equal(idx[safe], ref_idx[safe])
-    assert (idx != ref_idx).sum() <= 2
+    # the mismatches that remain (device tanhf vs the CPU's tanh in the last ulp, exactly at a rounding boundary) are listed and
+    # pinned: at most two of the sweep's values, each within 4e-6 of a boundary
+    bad = np.nonzero(idx != ref_idx)[0]
+    for i in bad:
+        print(f"fsq kat {tag}: z = {z[i].cpu().numpy()} index {idx[i]} != reference {ref_idx[i]}; bounded {bounded[i].numpy()} vs {ref_b[i].numpy()}; margin {margin[i]:.2e}")
+    print(f"fsq kat {tag}: {len(bad)} of {len(idx)} indices differ from the reference")
+    assert len(bad) <= 2 and all(margin[i] <= 4e-6 for i in bad)
     assert np.array_equal(codes.cpu().numpy()[safe], d[f"codes_{tag}"][safe])
     n = int(np.prod(levels))
     cb = f.indices_to_codes(torch.arange(n, dtype=torch.int32, device=DEV)).cpu().numpy()

@@ -4,10 +4,14 @@
 Parity bars
   * fp32 compute  : token indices BIT-EXACT vs the reference on every fixture token whose FSQ rounding margin
                     0.5-|b-round(b)| exceeds 1e-3 (all tokens of the small fixtures); z / pixels to ~1e-3.
-  * bf16 compute  : (the configuration the benchmark runs) indices exact on tokens with margin > TAU_BF16, raw match
-                    rate reported and bounded below; pixels within PIX_TOL_BF16 (max-abs on a [-1,1]-scaled signal with
-                    std ~1.9) and 2.5% relative Frobenius error.  SURVEY.md R8: the reference's own bf16 vs fp32 runs
-                    agree on only 94.9% of indices, so bf16 can not be bit-exact by construction.
+  * bf16 compute  : (the configuration the benchmark runs) can not be bit-exact against an fp32 run (round() after tanh;
+                    SURVEY.md R8: the reference's own bf16 run agrees with its fp32 run on 80-82 % of the fixture tokens).  The
+                    bar is the YARDSTICK - a bf16 execution of the same model on the same inputs (fixture keys *_refbf16: the
+                    reference's own modules in bf16; where no fixture exists, the oracle run in bf16): with FIXED thresholds
+                    (TAU_LIST) the HIP path may not have more index mismatches than the yardstick (+ BF16_SLACK), its mean / max
+                    pre-rounding error may not exceed the yardstick's by more than 15 % / 25 %, and indices must be exact
+                    wherever the margin exceeds the yardstick's own maximum error (a constant of the fixture, not of this path).
+                    Pixels within PIX_TOL_BF16 (max-abs on a [-1,1]-scaled signal with std ~1.9) and 2.5 % relative.
 """
 import os
 from types import SimpleNamespace
@@ -26,8 +30,38 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda:0"
 LEVELS = [7, 5, 5, 5, 5]
 TAU_F32 = 1e-3
-TAU_BF16 = 0.08
+TAU_LIST = (0.08, 0.16)     # fixed rounding-margin thresholds of the bf16 mismatch counts (2x and 4x the mean bf16 error)
 PIX_TOL_BF16 = 0.25
+
+
+def bf16_slack(n_tokens):
+    """index mismatches are coin flips near rounding boundaries: allow 1.5 % of the tokens, at least two"""
+    return max(2, int(round(0.015 * n_tokens)))
+
+
+def assert_bf16_not_worse_than_yardstick(name, idx, bounded, ref_idx, ref_b, yard_idx, yard_b, small_sample=False):
+    """idx / bounded: HIP bf16 run; ref_*: fp32 reference; yard_*: a bf16 execution of the same model (reference modules or oracle).
+    small_sample: a few dozen tokens and the oracle's bf16 run as yardstick (two bf16 executions of one model differ from each
+    other by as much as each differs from fp32): error ratios 1.35 / 1.6 instead of 1.15 / 1.25, one more token of slack."""
+    r_mean, r_max, extra = (1.35, 1.6, 1) if small_sample else (1.15, 1.25, 0)
+    idx, ref_idx, yard_idx = (np.asarray(a) for a in (idx, ref_idx, yard_idx))
+    margin = O.fsq_margin(ref_b).numpy()
+    err, yerr = (bounded.float() - ref_b).abs(), (yard_b.float() - ref_b).abs()
+    n = idx.size
+    raw, yraw = int((idx != ref_idx).sum()), int((yard_idx != ref_idx).sum())
+    print(f"{name} bf16 vs fp32 reference: mismatches HIP {raw}/{n} | yardstick {yraw}/{n}; mean|bounded err| HIP {float(err.mean()):.4f} | "
+          f"yardstick {float(yerr.mean()):.4f}; max HIP {float(err.max()):.4f} | yardstick {float(yerr.max()):.4f}")
+    assert raw <= yraw + bf16_slack(n) + extra
+    for tau in TAU_LIST:
+        safe = margin > tau
+        mine, yard = int((idx[safe] != ref_idx[safe]).sum()), int((yard_idx[safe] != ref_idx[safe]).sum())
+        print(f"   margin > {tau}: {int(safe.sum())} tokens, mismatches HIP {mine} | yardstick {yard}")
+        assert mine <= yard + bf16_slack(int(safe.sum())) + extra
+    assert float(err.mean()) <= r_mean * float(yerr.mean())
+    assert float(err.max()) <= r_max * float(yerr.max())
+    # exact wherever the fp32 value is further from a rounding boundary than the YARDSTICK's maximum error
+    safe = margin > float(yerr.max())
+    assert np.array_equal(idx[safe], ref_idx[safe])
 
 
 def config(levels=LEVELS, enc="tiny", dec="tiny"):
@@ -97,22 +131,8 @@ def test_bf16_vs_reference(name):
     model = build(torch.bfloat16)
     shapes, counts, clips = fixture_inputs(d, torch.bfloat16)
     codes, idx, bounded, recon = run(model, clips, counts)
-    ref_b = torch.from_numpy(d["bounded"])
-    margin = O.fsq_margin(ref_b).numpy()
-    raw = float((idx == d["indices"]).mean())
-    raw_ref16 = float((d["indices_refbf16"] == d["indices"]).mean())
-    err = (bounded - ref_b).abs()
-    err_ref16 = (torch.from_numpy(d["bounded_refbf16"]) - ref_b).abs()
-    print(f"{name} bf16: index match vs fp32 reference: HIP {raw:.4f} | reference-in-bf16 {raw_ref16:.4f}; "
-          f"mean|bounded err| HIP {float(err.mean()):.4f} | ref-bf16 {float(err_ref16.mean()):.4f}; "
-          f"max HIP {float(err.max()):.4f} | ref-bf16 {float(err_ref16.max()):.4f}")
-    # raw agreement is a count of coin flips near rounding boundaries: allow 3 % or one token and a half on the small fixtures
-    # (17 tokens); the error of the continuous value underneath is the real bar
-    assert raw >= raw_ref16 - max(0.03, 1.5 / idx.size)
-    assert float(err.mean()) <= 1.15 * float(err_ref16.mean())
-    # exact wherever the fp32 value is further from a rounding boundary than the observed bf16 error
-    safe = margin > float(err.max()) + 1e-6
-    assert np.array_equal(idx[safe], d["indices"][safe])
+    assert_bf16_not_worse_than_yardstick(name, idx, bounded, d["indices"], torch.from_numpy(d["bounded"]), d["indices_refbf16"],
+                                         torch.from_numpy(d["bounded_refbf16"]))
     # decoder alone on the reference's fp32-run codes (independent of index flips): pixel error no worse than the
     # reference's own bf16 decoder (x1.15) and < PIX_TOL_BF16 absolute / 2.5% relative
     ref_codes = O.fsq_indices_to_codes(torch.from_numpy(d["indices"]), LEVELS).to(torch.bfloat16).to(DEV)
@@ -240,6 +260,32 @@ def test_blocks_kat_fp32():
     _lib.check(lib.ttv_linear_geglu(xn.data_ptr(), dm, w[p + "ffd_layer.1.w12.weight"].data_ptr(), dm, h.data_ptr(), I, Lr, I, dm, 1, S), "g")
     _lib.check(lib.ttv_linear(h.data_ptr(), I, w[p + "ffd_layer.1.w3.weight"].data_ptr(), I, None, None, out.data_ptr(), dm, Lr, dm, I, 1, S), "o")
     np.testing.assert_allclose(out.cpu().numpy(), d["ffd1"], rtol=1e-3, atol=1e-3)
+    # the whole 4-layer stack (layer 0 pre-LN residual, layers >= 1 KEEL: x = post_ln(alpha * x + f(x)), alpha = 2 * layers,
+    # transformer.py:126-146), chained from the single ops, against the reference's `model_layers(x)`
+    alpha = 8.0
+    xs = x.clone()
+    y32 = torch.empty(Lr, dm, device=DEV)
+    tbl = plan.attention_table(4, 2)
+
+    def wt(name):
+        return w[p + name].data_ptr()
+    for i in range(4):
+        _lib.check(lib.ttv_rmsnorm(xs.data_ptr(), 1, dm, None, xn.data_ptr(), 1, dm, None, wt(f"attn_layer.{i}.pre_ln.weight"), Lr, dm, 1e-5, S), "n")
+        _lib.check(lib.ttv_linear_qkv_rope(xn.data_ptr(), dm, wt(f"attn_layer.{i}.to_qkv.weight"), dm, qkv.data_ptr(), 2 * dm + 2 * gq, Lr, dm, gq, plan.rope_cs.data_ptr(), 1, S), "q")
+        _lib.check(lib.ttv_attention(qkv.data_ptr(), 2 * dm + 2 * gq, ao.data_ptr(), dm, plan.cu_dev.data_ptr(), tbl.data_ptr(), tbl.shape[0], 4, 2, 64, 1, 1, S), "a")
+        if i == 0:
+            _lib.check(lib.ttv_linear_residual(ao.data_ptr(), dm, wt("attn_layer.0.out_proj.weight"), dm, xs.data_ptr(), dm, 1.0, xs.data_ptr(), dm, 0, Lr, dm, dm, 1, S), "o")
+        else:
+            _lib.check(lib.ttv_linear_residual(ao.data_ptr(), dm, wt(f"attn_layer.{i}.out_proj.weight"), dm, xs.data_ptr(), dm, alpha, y32.data_ptr(), dm, 1, Lr, dm, dm, 1, S), "o")
+            _lib.check(lib.ttv_rmsnorm(y32.data_ptr(), 1, dm, None, xs.data_ptr(), 1, dm, None, wt(f"attn_post_ln.{i - 1}.weight"), Lr, dm, 1e-5, S), "n")
+        _lib.check(lib.ttv_rmsnorm(xs.data_ptr(), 1, dm, None, xn.data_ptr(), 1, dm, None, wt(f"ffd_layer.{i}.norm.weight"), Lr, dm, 1e-5, S), "n")
+        _lib.check(lib.ttv_linear_geglu(xn.data_ptr(), dm, wt(f"ffd_layer.{i}.w12.weight"), dm, h.data_ptr(), I, Lr, I, dm, 1, S), "g")
+        if i == 0:
+            _lib.check(lib.ttv_linear_residual(h.data_ptr(), I, wt("ffd_layer.0.w3.weight"), I, xs.data_ptr(), dm, 1.0, xs.data_ptr(), dm, 0, Lr, dm, I, 1, S), "o")
+        else:
+            _lib.check(lib.ttv_linear_residual(h.data_ptr(), I, wt(f"ffd_layer.{i}.w3.weight"), I, xs.data_ptr(), dm, alpha, y32.data_ptr(), dm, 1, Lr, dm, I, 1, S), "o")
+            _lib.check(lib.ttv_rmsnorm(y32.data_ptr(), 1, dm, None, xs.data_ptr(), 1, dm, None, wt(f"ffd_post_ln.{i - 1}.weight"), Lr, dm, 1e-5, S), "n")
+    np.testing.assert_allclose(xs.cpu().numpy(), d["stack"], rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("size", ["small", "base", "large"])
@@ -251,7 +297,7 @@ def test_other_model_sizes_match_oracle(size, dtype):
     m = TiTok(config(enc=size, dec=size))
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV, dtype).eval()
-    shapes, counts = [(4, 16, 16), (8, 16, 24)], [3, 6]
+    shapes, counts = [(4, 16, 16), (8, 16, 24), (4, 32, 16)], [16, 24, 20]
     clips_cpu = synthetic_clips(shapes, seed=13)
     with torch.no_grad():
         ref_recon, ref_idx, ref_z, ref_b = O.titok_forward(clips_cpu, counts, sd, LEVELS, size, size)
@@ -265,9 +311,11 @@ def test_other_model_sizes_match_oracle(size, dtype):
         assert torch.equal(dd["indices"].cpu(), ref_idx)
         assert berr < 2e-3 and perr < 5e-3 * max(1.0, scale)
     else:
-        safe = O.fsq_margin(ref_b) > berr + 1e-6
-        assert torch.equal(dd["indices"].cpu()[safe], ref_idx[safe])
-        assert berr < 0.6 and perr < 0.08 * max(1.0, scale)
+        with torch.no_grad():    # yardstick: the oracle executed in bf16 on the same inputs
+            _r, y_idx, _z, y_b = O.titok_forward([c.to(torch.bfloat16) for c in clips_cpu], counts, sd, LEVELS, size, size)
+        assert_bf16_not_worse_than_yardstick(size, dd["indices"].cpu().numpy(), m.last_bounded.cpu(), ref_idx.numpy(), ref_b, y_idx.numpy(), y_b,
+                                             small_sample=True)
+        assert perr < 0.08 * max(1.0, scale)
 
 
 def test_ragged_dynamic_batches_fp32_match_oracle():
@@ -344,7 +392,7 @@ def test_sampling_range_extremes_fp32_match_oracle():
 
 def test_sampling_range_extremes_bf16_close_to_oracle():
     """Same corners through the bf16 kernels (fused tail, gathered proj_in, scattered proj_out, LDS-DMA attention with an odd
-    number of key tiles): indices exact wherever the fp32 value is further from a rounding boundary than the observed error."""
+    number of key tiles): not worse than a bf16 execution of the oracle on the same inputs (fixed thresholds, see the header)."""
     shapes, counts = [(16, 168, 168), (8, 128, 128), (16, 168, 168)], [128, 1, 1]
     clips32 = synthetic_clips(shapes, seed=77, dtype=torch.float32, device="cpu")
     model = build(torch.bfloat16)
@@ -353,11 +401,93 @@ def test_sampling_range_extremes_bf16_close_to_oracle():
         codes, od = model.encode(clips, counts, want_bounded=True)
         recon = model.decode(codes, counts, shapes)
     sd = seeded_titok_state(0)
-    _r, ref_idx, _z, ref_bounded = O.titok_forward([c.to(torch.bfloat16).float() for c in clips32], counts, sd, LEVELS)
-    berr = float((model.last_bounded.float().cpu() - ref_bounded).abs().max())
-    safe = O.fsq_margin(ref_bounded) > berr + 1e-6
-    assert berr < 0.6
-    assert torch.equal(od["indices"].cpu()[safe], ref_idx[safe])
+    with torch.no_grad():
+        _r, ref_idx, _z, ref_bounded = O.titok_forward([c.to(torch.bfloat16).float() for c in clips32], counts, sd, LEVELS)
+        _r, y_idx, _z, y_b = O.titok_forward([c.to(torch.bfloat16) for c in clips32], counts, sd, LEVELS)    # yardstick: the oracle in bf16
+    assert_bf16_not_worse_than_yardstick("sampling corners", od["indices"].cpu().numpy(), model.last_bounded.cpu(), ref_idx.numpy(),
+                                         ref_bounded, y_idx.numpy(), y_b, small_sample=True)
     dec_ref = O.titok_decode_indices(od["indices"].cpu(), shapes, counts, sd, LEVELS)
     for r, ref in zip(recon, dec_ref):
         assert float((r.float().cpu() - ref).abs().max()) < PIX_TOL_BF16 * 1.5
+
+
+def test_batch32_bf16_equals_eight_batches_of_four_and_the_fixture(monkeypatch):
+    """BASELINE config #2 at its full size (32 x 16x128x128, K = 128: L = 36 864 rows, the tile shapes the benchmark selects).
+    With one attention work-table regime for both sizes (full items only) the batch equals eight batch-4 calls bit for bit - a
+    clip's result does not depend on its batch mates - and its first four clips are the fixture's: same parity statistics as
+    the batch-4 fixture test."""
+    monkeypatch.setenv("TTV_ATTN_SPLIT", "0")
+    d = np.load(os.path.join(G, "titok_cfg1.npz"))
+    model = build(torch.bfloat16)
+    shapes, counts = [(16, 128, 128)] * 32, [128] * 32
+    clips = synthetic_clips(shapes, seed=int(d["clip_seed"]), dtype=torch.bfloat16, device=DEV)
+    with torch.no_grad():
+        codes, od = model.encode(clips, counts, want_bounded=True)
+        bounded = model.last_bounded.clone()
+        recon = model.decode(codes, counts, shapes)
+        for j in range(8):
+            c4, o4 = model.encode(clips[4 * j:4 * j + 4], counts[:4], want_bounded=True)
+            assert torch.equal(o4["indices"], od["indices"][512 * j:512 * (j + 1)])
+            assert torch.equal(model.last_bounded, bounded[512 * j:512 * (j + 1)])
+            r4 = model.decode(c4, counts[:4], shapes[:4])
+            for a, b in zip(r4, recon[4 * j:4 * j + 4]):
+                assert torch.equal(a, b)
+    assert_bf16_not_worse_than_yardstick("cfg1 at batch 32", od["indices"][:512].cpu().numpy(), bounded[:512].cpu(), d["indices"],
+                                         torch.from_numpy(d["bounded"]), d["indices_refbf16"], torch.from_numpy(d["bounded_refbf16"]))
+
+
+def test_batch32_fp32_indices_equal_the_reference():
+    """The float32 towers (exact-fp32 MFMA kernels) at the benchmark batch: every token of the fixture's four clips whose rounding
+    margin exceeds 1e-3 has the reference's index (the same check bench.py reports as parity.fp32_exact)."""
+    d = np.load(os.path.join(G, "titok_cfg1.npz"))
+    model = build(torch.float32)
+    shapes, counts = [(16, 128, 128)] * 32, [128] * 32
+    clips = synthetic_clips(shapes, seed=int(d["clip_seed"]), dtype=torch.float32, device=DEV)
+    with torch.no_grad():
+        codes, od = model.encode(clips, counts, want_bounded=True)
+    idx = od["indices"][:512].cpu().numpy()
+    margin = O.fsq_margin(torch.from_numpy(d["bounded"])).numpy()
+    safe = margin > TAU_F32
+    assert np.array_equal(idx[safe], d["indices"][safe])
+    assert (idx != d["indices"]).sum() <= 2, (idx != d["indices"]).sum()
+    np.testing.assert_allclose(model.last_bounded[:512].cpu().numpy(), d["bounded"], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_token_and_patch_initialisation_rows(dtype):
+    """Row a6 of the scope table: the input of layer 0 (blocks.py:95-97 encoder, :165-167 decoder) from the two row kernels alone -
+    constant rows RMSNorm(mask_token * 1) * gain and the decoder's latent rows RMSNorm(proj_in(codes) + mask_token) * gain -
+    against the same expressions evaluated in float64 on the host."""
+    from titok_video_amd import _lib
+    lib, S = _lib.lib(), _lib.stream_ptr(torch.device(DEV))
+    code = _lib.dtype_code(dtype)
+    sd = seeded_titok_state(0)
+    dm, C, rows = 256, 5, 37
+    gen = torch.Generator().manual_seed(9)
+    rows_map = torch.randperm(64, generator=gen)[:rows].to(torch.int32)
+    x = torch.zeros(64, dm, dtype=dtype, device=DEV)
+    mt = sd["encoder.mask_token"].reshape(1).to(DEV)
+    g_t = sd["encoder.ln_pre_t.weight"].to(DEV)
+    rm_dev = rows_map.to(DEV)
+    _lib.check(lib.ttv_fill_const_rows(x.data_ptr(), code, dm, rm_dev.data_ptr(), rows, dm, mt.data_ptr(), g_t.data_ptr(), 1e-5, S), "fill")
+    m = mt.to(dtype).double().cpu()
+    ref = (m / torch.sqrt(m * m + 1e-5)) * g_t.double().cpu()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    got = x.double().cpu()
+    assert float((got[rows_map.long()] - ref[None, :]).abs().max()) < tol
+    untouched = torch.ones(64, dtype=torch.bool)
+    untouched[rows_map.long()] = False
+    assert float(got[untouched].abs().max()) == 0.0
+    # decoder latent rows
+    codes = O.fsq_indices_to_codes(torch.randint(0, 4375, (rows,), generator=gen, dtype=torch.int32), LEVELS).to(dtype)
+    wv, bv = sd["decoder.proj_in.weight"].to(dtype), sd["decoder.proj_in.bias"].to(dtype)
+    mtd, gd = sd["decoder.mask_token"].reshape(1).to(DEV), sd["decoder.ln_pre_t.weight"].to(DEV)
+    x.zero_()
+    codes_d, wv_d, bv_d = codes.to(DEV), wv.to(DEV), bv.to(DEV)     # kept alive: raw pointers go to the library
+    _lib.check(lib.ttv_decoder_embed(codes_d.data_ptr(), C, wv_d.data_ptr(), bv_d.data_ptr(), mtd.data_ptr(), gd.data_ptr(), x.data_ptr(),
+                                     code, dm, rm_dev.data_ptr(), rows, dm, 1e-5, S), "embed")
+    torch.cuda.synchronize()
+    hh = codes.double() @ wv.double().t() + bv.double() + mtd.to(dtype).double().cpu()
+    ref = hh * torch.rsqrt(hh.pow(2).mean(-1, keepdim=True) + 1e-5) * gd.double().cpu()
+    got = x.double().cpu()[rows_map.long()]
+    assert float((got - ref).abs().max()) < (2e-5 if dtype == torch.float32 else 6e-2), float((got - ref).abs().max())

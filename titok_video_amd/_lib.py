@@ -98,6 +98,8 @@ SYMBOLS = {
     "ttv_layer_tail_fused": (C.c_int, [vp, C.c_int, vp, f32, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int,
                                        C.c_int, vp, vp]),
     "ttv_mlp_fused": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_fill_const_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, f32, vp]),
+    "ttv_decoder_embed": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, f32, vp]),
     "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                    C.c_int, C.c_int, vp]),

@@ -276,6 +276,18 @@ int ttv_layer_tail_fused(const void* ao, int ldao, const float* attn_post_gain, 
                         next ? &nx : nullptr, (hipStream_t)stream);
 }
 
+int ttv_fill_const_rows(void* x, int dtype, int ld, const int32_t* rows_map, int rows, int width, const float* mask_token,
+                        const float* gain, float eps, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (x && rows_map && mask_token && gain), "fill_const_rows: null buffer");
+  return ttvk_fill_const_rows(x, dtype, ld, rows_map, rows, width, mask_token, gain, eps, (hipStream_t)stream);
+}
+
+int ttv_decoder_embed(const void* codes, int token_size, const void* w, const void* bias, const float* mask_token, const float* gain,
+                      void* x, int dtype, int ld, const int32_t* rows_map, int rows, int width, float eps, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (codes && w && bias && mask_token && gain && x && rows_map), "decoder_embed: null buffer");
+  return ttvk_dec_embed(codes, token_size, w, bias, mask_token, gain, x, dtype, ld, rows_map, rows, width, eps, (hipStream_t)stream);
+}
+
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks, int n_qblocks,
                   int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream) {
   TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention: null buffer");

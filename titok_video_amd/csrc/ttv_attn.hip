@@ -67,11 +67,10 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 // when a tile raises the maximum (rare after the first tiles) the tile's scores, the running state and the start vector are shifted.
 // TAPE: the training forward - additionally writes the log-sum-exp per (row, head) and, with the gate, the ungated output.
 //
-// VALU budget.  The kernel is bound by the vector issue port (SQ_ACTIVE_INST_VALU ~ 80 % of the wave-cycles at three waves per
-// SIMD, profiles/r02_attn_sq_*.csv), so everything that is not an exp2, a bf16 pack or an MFMA has been moved off it:
-//   * row sums ride on the matrix pipe: a third O^T tile whose V^T operand is a constant "ones" row (A[row 0][k] = 1) accumulates
-//     l = sum_k P[k][q] in its row 0 - 4 extra MFMAs per tile (the pipe is < 40 % busy) instead of 32 v_add_f32, and the sum is
-//     taken over the same bf16-rounded P that enters the numerator;
+// What bounds it (profiles/r02_attn_*): a wave needs ~2 000 cycles per 64-key tile on its own (in-kernel stamps: barrier + DMA wait
+// 15 %, DMA issue + K fragment reads + S MFMAs 28 %, S completion + row maximum 11 %, 32 exp2 + pack 25 %, V reads + PV MFMAs 21 %)
+// and ~2 900 with three waves per SIMD: the chain of dependent phases of ONE wave, not a saturated pipe (matrix pipe ~35-45 %
+// busy, vector issue ~35 %).  Everything off that chain that could be moved has been:
 //   * the running reference of the softmax moves only when a score exceeds it by more than `defer_thr` (see below);
 //   * the DMA source of a tile is a scalar base (advanced per tile on the scalar unit) plus lane-constant offsets: no per-tile
 //     address arithmetic on the vector unit except in a sequence's last, partial tile;
@@ -172,10 +171,18 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
     const uint32_t dk__ = kl_lds + (buf_) * (KB * 128) + wave_s * (1024 * DPW);                                  \
     const uint32_t dv__ = vl_lds + (buf_) * (KB * 128) + wave_s * (1024 * DPW);                                  \
     if (key0__ + KB <= S) {                                                                                      \
-      DMA16(dK0, kb__, dk__);                                                                                    \
-      if (DPW == 2) DMA16(dK1, kb__, dk__ + 1024);                                                               \
-      DMA16(dV0, vb__, dv__);                                                                                    \
-      if (DPW == 2) DMA16(dV1, vb__, dv__ + 1024);                                                               \
+      unsigned keep__;                                                                                           \
+      if (DPW == 2)                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"        \
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"                            \
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"                            \
+                     "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\ts_mov_b32 m0, %0"           \
+                     : "=&s"(keep__) : "v"(dK0), "v"(dK1), "v"(dV0), "v"(dV1), "s"(kb__), "s"(vb__), "s"(dk__),       \
+                       "s"(dk__ + 1024), "s"(dv__), "s"(dv__ + 1024) : "memory");                                   \
+      else                                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"        \
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\ts_mov_b32 m0, %0"            \
+                     : "=&s"(keep__) : "v"(dK0), "v"(dV0), "s"(kb__), "s"(vb__), "s"(dk__), "s"(dv__) : "memory");    \
     } else {                                                                                                     \
       const int lim__ = S - 1 - key0__;                                                                          \
       const int g0__ = drow0 < lim__ ? drow0 : lim__, g1__ = drow1 < lim__ ? drow1 : lim__;                      \
@@ -218,7 +225,14 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
   // to copy its start vector into its accumulator first
   f32x16 negm0 = zero16;
   // third O^T tile: its V^T operand is the constant row A[0][k] = 1 (lanes 0 and 32), so its row 0 accumulates the row sums
-  constexpr bool MSUM = NE == 1;   // the 8-wave paired kernel is held to 128 registers: it keeps the vector-unit row sums
+  // ATTN_MSUM (opt-in build flag): row sums on the matrix pipe instead of 32 v_add_f32 per tile.  Measured neutral to -1 % end to
+  // end (28.1 k vs 28.4 k clips/s): the 4 extra MFMAs per tile load the pipe the waves of a SIMD share as much as the adds load
+  // the issue port, and cost 9 more registers.  Never for the 8-wave paired kernel (held to 128 registers).
+#ifdef ATTN_MSUM
+  constexpr bool MSUM = NE == 1;
+#else
+  constexpr bool MSUM = false;
+#endif
   f32x16 o_sum = zero16;
   const bf16_t one_or_zero = (bf16_t)(r == 0 ? 1.0f : 0.0f);
   const bf16x8 ones_frag = {one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero};
@@ -282,12 +296,23 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
         }
     }
     // ---- online softmax (fp32) ----
-    float mx = s_acc[0][0];
+    // four independent chains (a single chain of 16 dependent v_max3 is pure latency for a wave that has nothing else to issue),
+    // then the two lane halves of a query exchange their maxima with one v_permlane32_swap (no LDS round trip)
+    float mx;
+    {
+      float c4[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s_acc[t][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int c = 0; c < 4; ++c) {
+        const int t = c >> 1, e0 = (c & 1) * 8;
+        float a = fmaxf(fmaxf(s_acc[t][e0], s_acc[t][e0 + 1]), s_acc[t][e0 + 2]);
+        a = fmaxf(fmaxf(a, s_acc[t][e0 + 3]), s_acc[t][e0 + 4]);
+        a = fmaxf(fmaxf(a, s_acc[t][e0 + 5]), s_acc[t][e0 + 6]);
+        c4[c] = fmaxf(a, s_acc[t][e0 + 7]);
+      }
+      const float m2 = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2), __builtin_bit_cast(unsigned, m2), false, false);
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
 #ifdef ATTN_STAMPS
     asm volatile("" ::"v"(mx));
 #endif
