@@ -491,3 +491,54 @@ def test_token_and_patch_initialisation_rows(dtype):
     ref = hh * torch.rsqrt(hh.pow(2).mean(-1, keepdim=True) + 1e-5) * gd.double().cpu()
     got = x.double().cpu()[rows_map.long()]
     assert float((got - ref).abs().max()) < (2e-5 if dtype == torch.float32 else 6e-2), float((got - ref).abs().max())
+
+
+def test_forward_pipeline_cold_start_unseen_shapes():
+    """A FRESH model (no packed weights yet) and batch shapes no plan exists for, submitted straight into a depth-2 pipeline:
+    the weight pack and the plans are built on the first stream while the second starts - it must wait for them (events recorded by
+    the pack / plan) - and the callers' input tensors are dropped right after submit (record_stream keeps them alive)."""
+    from titok_video_amd.pipeline import ForwardPipeline
+    specs = [([(4, 24, 40), (8, 16, 16)], [4, 6]), ([(8, 40, 24)], [11]), ([(4, 8, 40), (4, 24, 8), (4, 16, 48)], [2, 2, 5]), ([(8, 24, 24)], [7]),
+             ([(4, 24, 40), (8, 16, 16)], [4, 6]), ([(12, 16, 8)], [3])]
+    cold = build(torch.bfloat16, seed=4)
+    pipe = ForwardPipeline(cold, depth=2)
+    tickets = []
+    for i, (shapes, counts) in enumerate(specs):
+        clips = synthetic_clips(shapes, seed=300 + i, dtype=torch.bfloat16, device=DEV)
+        tickets.append(pipe.submit(clips, counts))
+        del clips                                              # the side stream may not have started reading them yet
+    outs = [pipe.result(t) for t in tickets]
+    torch.cuda.synchronize()
+    warm = build(torch.bfloat16, seed=4)
+    for i, ((shapes, counts), (recon, info)) in enumerate(zip(specs, outs)):
+        clips = synthetic_clips(shapes, seed=300 + i, dtype=torch.bfloat16, device=DEV)
+        with torch.no_grad():
+            r0, o0 = warm(clips, counts)
+        assert torch.equal(o0["indices"], info["indices"])
+        for a, b in zip(r0, recon):
+            assert torch.equal(a, b)
+
+
+def test_weight_updates_through_data_reach_the_kernels():
+    """`.data` writes do not bump a parameter's version counter, so the packed-weight cache cannot see them: init_weights (which
+    writes through .data) and load_state_dict invalidate the packs themselves, other `.data` updates call invalidate_packs()."""
+    from titok_video_amd.model.base.utils import init_weights
+    model = build(torch.bfloat16)
+    shapes, counts = [(4, 16, 16), (8, 16, 24)], [3, 6]
+    clips = synthetic_clips(shapes, seed=8, dtype=torch.bfloat16, device=DEV)
+    with torch.no_grad():
+        r0, _ = model(clips, counts)
+        model.decoder.proj_out.weight.data.mul_(2.0)           # invisible to the version counters
+        model.decoder.invalidate_packs()
+        r1, _ = model(clips, counts)
+        assert not torch.equal(r0[0], r1[0])
+        model.decoder.proj_out.weight.mul_(0.5)                # in-place under no_grad: bumps the version, repacked by itself
+        r2, _ = model(clips, counts)
+        assert torch.equal(r0[0], r2[0])
+        model.apply(init_weights)                              # trunc_normal_(weight.data): must not leave the old packs in use
+        r3, o3 = model(clips, counts)
+        assert not torch.equal(r0[0], r3[0])
+        fresh = TiTok(config()).to(DEV, torch.bfloat16).eval()
+        fresh.load_state_dict(model.state_dict(), strict=True)
+        r4, o4 = fresh(clips, counts)
+        assert torch.equal(o3["indices"], o4["indices"]) and torch.equal(r3[0], r4[0])

@@ -63,11 +63,31 @@ class CodebookLogger(nn.Module):
         return usage, entropy
 
     def get_scores(self, all_reduce: bool = True) -> Optional[dict]:
-        if not self.is_score_ready():
+        """Scores once the FIFO is full, else None.  Under torch.distributed the decision is COLLECTIVE: ranks receive different
+        numbers of clips per step (token-budget batching), so their FIFOs fill on different steps; every rank therefore enters the
+        same two small all-reduces on every call - the number of ranks that are ready, then (only if all are) the histogram - and
+        all ranks return scores on the same call.  A rank that is full keeps its newest `capacity` samples while it waits."""
+        dist_on = all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized()
+        ready = self.is_score_ready()
+        if dist_on:
+            dev = self.codebook_indices[0].device if self.codebook_indices else None
+            if dev is None or torch.distributed.get_backend(self.process_group) == "gloo":
+                dev = torch.device("cpu")
+            elif dev.type != "cuda":
+                dev = torch.device("cuda", torch.cuda.current_device())
+            flag = torch.tensor([1 if ready else 0], dtype=torch.int64, device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+            ready = bool(int(flag.item()))
+        if not ready:
             return None
         counts = self.histogram()
-        if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(counts, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        if dist_on:
+            if counts.is_cuda and torch.distributed.get_backend(self.process_group) == "gloo":
+                host = counts.cpu()
+                torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+                counts = host
+            else:
+                torch.distributed.all_reduce(counts, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
         usage, entropy = self.scores_from_counts(counts)
         self.codebook_indices = []
         return {"codebook/usage_percent": usage, "codebook/entropy": entropy}

@@ -50,8 +50,10 @@ class SyntheticClipStream:
 
 
 def dynamic_batches(samples, patch: Sequence[int], token_range: Sequence[int], max_seq_len: int, seed: int = 0,
-                    max_grid: Optional[Sequence[int]] = None, device=None) -> Iterator[Dict]:
-    """Token-budget batching with the reference's policy (video_dataset.py:130-172): never exceed `max_seq_len` packed rows."""
+                    max_grid: Optional[Sequence[int]] = None, device=None, drop_last: bool = False) -> Iterator[Dict]:
+    """Token-budget batching with the reference's policy (video_dataset.py:130-172): never exceed `max_seq_len` packed rows.
+    drop_last: the reference never emits the clips left over when the stream ends (its generator only yields when the NEXT clip
+    would overflow the budget); True reproduces that, False (default, inference / tests) also emits the trailing partial batch."""
     if max_grid is not None and math.prod(x // y for x, y in zip(max_grid, patch)) + token_range[1] > max_seq_len:
         raise ValueError("max_grid/patch + token_range[1] must fit in max_seq_len")
     rng = random.Random(seed)
@@ -67,8 +69,28 @@ def dynamic_batches(samples, patch: Sequence[int], token_range: Sequence[int], m
         cur += grid + k
         chunk.append(sample)
         counts.append(k)
-    if chunk:
+    if chunk and not drop_last:
         yield _collate(chunk, counts, device)
+
+
+def equal_steps(batches: Iterator[Dict], process_group=None) -> Iterator[Dict]:
+    """Data-parallel training loop guard: yield this rank's batches only while EVERY rank still has one.  Token-budget batching
+    gives the ranks different numbers of batches for the same number of clips; the per-step gradient all-reduce must be entered
+    by all ranks or by none, so the epoch ends (collectively) when the first rank runs out - one 8-byte all-reduce per step."""
+    import torch.distributed as dist
+    it = iter(batches)
+    on = dist.is_available() and dist.is_initialized()
+    while True:
+        nxt = next(it, None)
+        if on:
+            dev = "cpu" if dist.get_backend(process_group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+            flag = torch.tensor([0 if nxt is None else 1], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+            if int(flag.item()) == 0:
+                return
+        elif nxt is None:
+            return
+        yield nxt
 
 
 def _collate(chunk: List[Dict], counts: List[int], device) -> Dict:

@@ -61,6 +61,9 @@ def _versions(params) -> tuple:
     return tuple((p.data_ptr(), p._version, p.dtype) for p in params)
 
 
+_PACK_CHECK = os.environ.get("TTV_PACK_CHECK", "0") == "1"
+
+
 class _Tower(nn.Module):
     kind = _lib.TTV_ENCODER
 
@@ -84,6 +87,7 @@ class _Tower(nn.Module):
         self._pack = None
         self._pack_key = None
         self._ws = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packs())
         return mlp_ratio
 
     # ---- weight packing -------------------------------------------------------------------------
@@ -104,12 +108,35 @@ class _Tower(nn.Module):
             cache[key] = self._patch_perm().to(device)
         return cache[key]
 
+    def invalidate_packs(self) -> None:
+        """Forget the packed weight copies.  The cache key is (storage pointer, tensor version, dtype) of every parameter, which
+        catches optimizer steps, load_state_dict and in-place ops under no_grad - but NOT writes through `.data` (they do not
+        bump the version counter: `p.data.mul_(2)`, `trunc_normal_(p.data)`, EMA by `p.data.copy_`).  Code that updates weights
+        that way calls this afterwards; `init_weights` and `load_state_dict` do it themselves.  TTV_PACK_CHECK=1 (debugging)
+        additionally compares a content checksum on every call."""
+        self._retire_pack()
+        self._pack_key = None
+
+    def _retire_pack(self) -> None:
+        """The old pack's memory goes back to the allocator of the stream that built it: every other stream that read it (forwards
+        in flight in a ForwardPipeline) must be finished from that stream's point of view first."""
+        old, self._pack = self._pack, None
+        if old is not None and old.device.type == "cuda":
+            cur = torch.cuda.current_stream(old.device)
+            for st in old.reader_streams.values():
+                if st != cur:
+                    cur.wait_stream(st)
+
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
         params = self._param_list()
         key = (dtype, str(device), _versions(params))
+        if _PACK_CHECK:
+            key = key + (float(sum(p.detach().double().sum() for p in params)),)
         if self._pack is None or self._pack_key != key:
+            self._retire_pack()
             self._pack = _WeightPack(self, dtype, device)
             self._pack_key = key
+        self._pack.use_on_current_stream()
         return self._pack
 
     def _dims(self, dtype_code: int) -> _lib.TowerDims:
@@ -230,8 +257,10 @@ class _WeightPack:
 
     def __init__(self, tower: _Tower, dtype: torch.dtype, device):
         keep: List[torch.Tensor] = []
-        self.dtype, self.device = dtype, device
+        self.dtype, self.device = dtype, torch.device(device)
         self.lin_tensors: List[torch.Tensor] = []     # compute-dtype linear weights in creation order (see transposed())
+        self.ready = None                              # event recorded on the building stream once every copy / pack kernel is queued
+        self.reader_streams = {}                       # stream id -> stream, of every stream a forward read this pack on
 
         def lin(p):
             t = p.detach().to(device=device, dtype=dtype).contiguous()
@@ -327,6 +356,20 @@ class _WeightPack:
         self.keep = keep
         self.kind, self.n_layers = tower.kind, n
         self._t = None
+        if self.device.type == "cuda":
+            self.build_stream = torch.cuda.current_stream(self.device)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self.build_stream)
+
+    def use_on_current_stream(self) -> None:
+        """Called by every forward: a stream other than the one that built the pack waits for the build (casts, folds, the
+        ttv_mlp_pack kernel) before its kernels read the buffers, and is remembered as a reader (see _Tower._retire_pack)."""
+        if self.ready is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.build_stream and cur.cuda_stream not in self.reader_streams:
+            cur.wait_event(self.ready)
+        self.reader_streams[cur.cuda_stream] = cur
 
     def transposed(self) -> "_lib.TowerWeightsT":
         """W^T copies for the data-gradient GEMMs of the backward pass (built on first use, per weight version)."""

@@ -62,3 +62,7 @@ def init_weights(module: nn.Module) -> None:
             nn.init.constant_(module.bias, 0)
         if module.weight is not None:
             nn.init.constant_(module.weight, 1.0)
+    # `.data` writes above do not bump the parameters' version counters: a tower drops its packed weight copies explicitly
+    # (model.apply(init_weights) visits the towers too)
+    if hasattr(module, "invalidate_packs"):
+        module.invalidate_packs()

@@ -14,9 +14,13 @@ benchmark batch (32 clips of 16x128x128, tiny): 20.9 k clips/s one batch at a ti
         ...
         recon, out = pipe.result(ticket)         # makes the CURRENT stream wait for that batch (no host sync)
 
-Not for the training step: there every step depends on the weights the previous one produced.  Call `drain()` before the model's
-weights are modified (optimizer step, load_state_dict): the packed weight copies of a tower are rebuilt when a parameter changes and
-the old copies must not be released while a batch that reads them is still in flight.
+Not for the training step: there every step depends on the weights the previous one produced.
+
+Shared, lazily built device state is ordered across the streams by the objects themselves: a tower's packed weights and a cached
+batch plan record an event on the stream that builds them and every other stream waits for it before its first use
+(`_WeightPack.use_on_current_stream`, `BatchPlan.use_on_current_stream`); when one of them is replaced or evicted, the releasing
+stream first waits for every stream that read it.  Input tensors are `record_stream`-ed on the side stream, so a caller may drop
+its references as soon as `submit` returns.  `drain()` is still the way to make the current stream wait for everything in flight.
 """
 from __future__ import annotations
 
@@ -55,6 +59,9 @@ class ForwardPipeline:
         s = self.streams[self._n % len(self.streams)]
         self._n += 1
         s.wait_stream(torch.cuda.current_stream(self.device))
+        for t in _tensors((args, kwargs)):
+            if t.is_cuda:
+                t.record_stream(s)       # the caller may drop its reference (`for clips in loader`) while the side stream still reads
         with torch.cuda.stream(s), torch.no_grad():
             out = self.fn(*args, **kwargs)
         done = torch.cuda.Event()

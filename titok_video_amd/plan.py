@@ -157,6 +157,10 @@ class BatchPlan:
                                                  base + 4 * offs[5], self.rope_cs.data_ptr(), self.total_rows,
                                                  _lib.stream_ptr(self.device))
             _lib.check(rc, "ttv_rope_table_build")
+            # the table is written by a kernel on the building stream: other streams wait for this event before their first use
+            self.build_stream = torch.cuda.current_stream(self.device)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self.build_stream)
         else:   # host tensors (CPU-side tests of the plan): same table, gathered with numpy
             rope = np.concatenate([_rope_clip_table(g, k, head_dim) for g, k in zip(grids, self.token_counts)], axis=0)
             self.rope_cs = torch.from_numpy(rope).to(self.device)
@@ -169,6 +173,25 @@ class BatchPlan:
             blocks64=base + 4 * offs[4], row_seq=base + 4 * offs[5], n_blocks64=self.n_blocks64)
         self._offs = offs
         self._attn = {}
+        self.reader_streams = {}
+
+    def use_on_current_stream(self) -> None:
+        """Stream safety of the cached plan (see ForwardPipeline): wait for the build on foreign streams, remember the readers."""
+        if self.device.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.build_stream and cur.cuda_stream not in self.reader_streams:
+            cur.wait_event(self.ready)
+        self.reader_streams[cur.cuda_stream] = cur
+
+    def retire(self) -> None:
+        """Before the tables are released (cache eviction): the releasing stream waits for every stream that read them."""
+        if self.device.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.reader_streams.values():
+            if st != cur:
+                cur.wait_stream(st)
 
     def attention_table(self, q_heads: int, kv_heads: int, split: Optional[bool] = None) -> torch.Tensor:
         """int32 [n,4] attention work table (sequence, first query row, q-head, mode) for this batch, XCD-aware.
@@ -271,9 +294,10 @@ def get_plan(pixel_grids, token_counts, patch, device) -> BatchPlan:
     plan = _plan_cache.get(key)
     if plan is None:
         if len(_plan_cache) >= _PLAN_CACHE_MAX:
-            _plan_cache.pop(next(iter(_plan_cache)))
+            _plan_cache.pop(next(iter(_plan_cache))).retire()
         plan = BatchPlan(key[0], key[1], key[2], device)
         _plan_cache[key] = plan
+    plan.use_on_current_stream()
     return plan
 
 
