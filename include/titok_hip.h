@@ -61,6 +61,20 @@ int ttv_fsq_forward(const ttv_fsq_params* p, const void* z, int z_dtype, int row
 int ttv_fsq_indices_to_codes(const ttv_fsq_params* p, const int32_t* indices, int rows, void* codes, int codes_dtype,
                              void* stream);
 
+/* ---- nearest-codebook-entry (L2) quantiser ---------------------------------------------------------------
+ * Not a reference component (the reference quantises with FSQ only); BASELINE.json's north_star / configs #4, #5 ask for it.  On
+ * the FSQ lattice implicit_codebook * (levels // 2) (fsq.py:73-76) applied to FSQ.bound(z) (fsq.py:78-83) it returns FSQ's indices
+ * (fsq.py:105-109) away from rounding ties; for learned / synthetic codebooks it is argmin_n ||z - c_n||^2 with the LOWEST index on
+ * exact ties (torch.argmin's rule).  z [rows, C], codebook [N, C] in `dtype` (fp32: exact-fp32 MFMA; bf16: bf16 MFMA, fp32 sums),
+ * C <= 64.  cnorm: fp32 [N] = ||c_n||^2 from ttv_vq_codebook_norms (once per codebook).  best_dist (optional) fp32 [rows]. */
+int ttv_vq_codebook_norms(const void* codebook, int dtype, int ld, int N, int C, float* cnorm, void* stream);
+/* workspace: ttv_vq_workspace_bytes(rows) bytes, 8-byte aligned (per-row merge keys of the codebook splits; cleared by the call). */
+int64_t ttv_vq_workspace_bytes(int rows);
+int ttv_vq_l2_argmin(const void* z, int dtype, int ldz, const void* codebook, int ldc, const float* cnorm, int rows, int N, int C,
+                     int32_t* indices, float* best_dist, void* workspace, int64_t workspace_bytes, void* stream);
+/* straight-through lookup: codes[r] = codebook[indices[r]] (the value the decoder sees; gradients pass to z unchanged). */
+int ttv_vq_lookup(const void* codebook, int dtype, int ldc, const int32_t* indices, int rows, int C, void* codes, int ldo, void* stream);
+
 /* ---- single ops (exported for parity tests; the tower entry points below chain them) ------------------ */
 
 /* RMSNorm (flash_attn RMSNorm as used at blocks.py:51-52,66 / transformer.py:42,77,122-123):

@@ -1,0 +1,108 @@
+"""Nearest-codebook-entry (L2) quantiser (csrc/ttv_vq.hip) - BASELINE.json north_star / configs #4, #5.  NOT a reference component
+(the reference quantises with FSQ only), so it is pinned through FSQ: on FSQ's own lattice it must return FSQ's indices - the
+reference-generated fsq_kat.npz fixture - and on synthetic codebooks it must equal the float64 cdist + argmin oracle
+(oracle/vq_oracle.py; lowest index on ties) wherever the two best distances are further apart than fp32 rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import titok_oracle as O
+from oracle import vq_oracle as V
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_lattice_argmin_is_fsq(tag):
+    """CPU: nearest lattice entry of the bounded vector == the reference's FSQ index (fixture from the unmodified fsq.py), except
+    where a bounded value sits at a rounding boundary."""
+    d = np.load(os.path.join(G, "fsq_kat.npz"))
+    levels = d[f"levels_{tag}"].tolist()
+    b = torch.from_numpy(d[f"bounded_{tag}"])
+    lat = V.fsq_lattice(levels)
+    assert lat.shape == (int(np.prod(levels)), len(levels))
+    idx, best, gap = V.l2_argmin(b, lat)
+    safe = O.fsq_margin(b) > 1e-4
+    assert int(safe.sum()) > 0.9 * len(safe)
+    assert torch.equal(idx[safe], torch.from_numpy(d[f"indices_{tag}"])[safe])
+    # lattice entries are the reference's implicit codebook times levels // 2
+    hw = torch.tensor(levels) // 2
+    assert torch.equal(lat, torch.from_numpy(d[f"codebook_{tag}"]) * hw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_lattice_argmin_is_fsq(tag):
+    from titok_video_amd.model.quantizer.fsq import FSQ
+    from titok_video_amd.model.quantizer.vq_l2 import L2Quantizer
+    d = np.load(os.path.join(G, "fsq_kat.npz"))
+    levels = d[f"levels_{tag}"].tolist()
+    f = FSQ(levels)
+    z = torch.from_numpy(d[f"z_{tag}"]).to(DEV)
+    vq = L2Quantizer(f.lattice_codebook()).to(DEV)
+    assert torch.equal(vq.codebook.detach().cpu(), V.fsq_lattice(levels))
+    bounded = f.bounded(z)
+    idx = vq.indices(bounded).cpu()
+    ref_b = torch.from_numpy(d[f"bounded_{tag}"])
+    safe = O.fsq_margin(ref_b) > 1e-4
+    assert torch.equal(idx[safe], torch.from_numpy(d[f"indices_{tag}"])[safe])
+    # and on the model's own FSQ kernel, token for token
+    _codes, dd = f(z)
+    assert torch.equal(idx[safe], dd["indices"].cpu()[safe])
+    # straight-through lookup returns lattice entries; scaled back they are FSQ's codes
+    q = vq.lookup(idx.to(DEV))
+    hw = (torch.tensor(levels) // 2).float().to(DEV)
+    assert torch.equal((q / hw).cpu()[safe], torch.from_numpy(d[f"codes_{tag}"])[safe])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C", [(8192, 32), (16384, 64), (1000, 7), (100, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hip_l2_argmin_matches_cdist_oracle(N, C, dtype):
+    """Synthetic codebooks of configs #4 / #5 (8192 x 32, 16384 x 64) plus ragged sizes (N not a multiple of the 128-entry chunk,
+    odd C).  Inputs are rounded to `dtype` first, so the oracle sees exactly what the kernel sees; indices must agree wherever the
+    runner-up is further away than the accumulated fp32 rounding (gap > 1e-4 x the best distance's scale), and on EVERY row the
+    kernel's pick must be within that rounding of the true minimum."""
+    from titok_video_amd.model.quantizer.vq_l2 import L2Quantizer
+    g = torch.Generator().manual_seed(N + C)
+    cb = torch.randn(N, C, generator=g).to(dtype)
+    rows = 3000
+    z = (torch.randn(rows, C, generator=g) * 1.2).to(dtype)
+    z[:64] = cb[torch.randint(0, N, (64,), generator=g)]            # exact hits: distance 0
+    if N >= 1000:
+        cb[777] = cb[12]                                            # an exact duplicate: the lower index must win
+        z[64:72] = cb[12]
+    vq = L2Quantizer(cb.float()).to(DEV)
+    idx, dist = vq.indices(z.to(DEV), want_distance=True)
+    idx, dist = idx.cpu(), dist.cpu().double()
+    ref_idx, ref_best, gap = V.l2_argmin(z.float(), cb.float())
+    scale = (z.double().pow(2).sum(1) + ref_best + 1.0)
+    tol = 2e-5 * scale if dtype == torch.float32 else 2e-5 * scale
+    safe = gap > tol
+    assert float(safe.float().mean()) > (0.97 if C > 1 else 0.85)     # one dimension, 100 entries: many near-ties
+    assert torch.equal(idx[safe], ref_idx[safe]), int((idx[safe] != ref_idx[safe]).sum())
+    picked = (z.double() - cb.double()[idx.long()]).pow(2).sum(1)
+    assert bool((picked <= ref_best + tol).all())
+    assert float((dist - picked).abs().max()) < 1e-3 * float(scale.max())
+    # exact hits: the entry itself, unless a neighbour is closer than fp32 can resolve (dense one-dimensional codebooks)
+    assert bool((idx[:64] == ref_idx[:64])[safe[:64]].all()) and bool((picked[:64] <= tol[:64]).all())
+    if N >= 1000:
+        assert bool((idx[64:72] == 12).all())
+
+
+@pytest.mark.gpu
+def test_l2_quantizer_module_straight_through():
+    from titok_video_amd.model.quantizer.vq_l2 import L2Quantizer
+    g = torch.Generator().manual_seed(3)
+    vq = L2Quantizer(torch.randn(512, 32, generator=g)).to(DEV)
+    z = torch.randn(200, 32, generator=g).to(DEV).requires_grad_(True)
+    codes, info = vq(z)
+    assert info["indices"].dtype == torch.int32 and codes.shape == z.shape
+    # z + (q - z) in fp32: equal to the entry up to one rounding
+    assert torch.allclose(codes.detach(), vq.codebook.detach()[info["indices"].long()], rtol=0, atol=1e-6)
+    w = torch.randn_like(codes)
+    (codes * w).sum().backward()
+    assert torch.equal(z.grad, w)                      # d codes / d z = identity (straight-through)

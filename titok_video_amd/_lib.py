@@ -84,6 +84,10 @@ SYMBOLS = {
     "ttv_version": (C.c_int, []),
     "ttv_fsq_forward": (C.c_int, [C.POINTER(FsqParams), vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
     "ttv_fsq_indices_to_codes": (C.c_int, [C.POINTER(FsqParams), vp, C.c_int, vp, C.c_int, vp]),
+    "ttv_vq_codebook_norms": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ttv_vq_workspace_bytes": (C.c_int64, [C.c_int]),
+    "ttv_vq_l2_argmin": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, vp]),
+    "ttv_vq_lookup": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ttv_rmsnorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, f32, vp]),
     "ttv_rope_apply": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_linear": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -182,6 +182,25 @@ int ttv_fsq_indices_to_codes(const ttv_fsq_params* p, const int32_t* indices, in
   return ttvk_fsq_indices_to_codes(p, indices, rows, codes, codes_dtype, (hipStream_t)stream);
 }
 
+int ttv_vq_codebook_norms(const void* codebook, int dtype, int ld, int N, int C, float* cnorm, void* stream) {
+  TTV_CHECK_ARG(N == 0 || (codebook && cnorm), "vq_codebook_norms: null buffer");
+  return ttvk_vq_norms(codebook, dtype, ld, N, C, cnorm, (hipStream_t)stream);
+}
+
+int64_t ttv_vq_workspace_bytes(int rows) { return ttvk_vq_workspace_bytes(rows); }
+
+int ttv_vq_l2_argmin(const void* z, int dtype, int ldz, const void* codebook, int ldc, const float* cnorm, int rows, int N, int C,
+                     int32_t* indices, float* best_dist, void* workspace, int64_t workspace_bytes, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (z && codebook && cnorm && indices), "vq_l2_argmin: null buffer");
+  TTV_CHECK_ARG(ldz >= C && ldc >= C, "vq_l2_argmin: leading dims smaller than the codebook dim");
+  return ttvk_vq_l2_argmin(z, dtype, ldz, codebook, ldc, cnorm, rows, N, C, indices, best_dist, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ttv_vq_lookup(const void* codebook, int dtype, int ldc, const int32_t* indices, int rows, int C, void* codes, int ldo, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (codebook && indices && codes), "vq_lookup: null buffer");
+  return ttvk_vq_lookup(codebook, dtype, ldc, indices, rows, C, codes, ldo, (hipStream_t)stream);
+}
+
 int ttv_rmsnorm(const void* in, int in_dtype, int ld_in, const int32_t* src_rows, void* out, int out_dtype, int ld_out,
                 const int32_t* dst_rows, const float* gain, int rows, int width, float eps, void* stream) {
   TTV_CHECK_ARG(rows >= 0 && (rows == 0 || (in && out && gain)), "rmsnorm: null buffer");

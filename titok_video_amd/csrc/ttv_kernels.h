@@ -72,6 +72,13 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
                    int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out = nullptr,
                    void* out_raw = nullptr);
 
+// ---- ttv_vq.hip (nearest-codebook-entry quantiser) ----
+int ttvk_vq_norms(const void* cb, int dtype, int ld, int N, int C, float* cnorm, hipStream_t s);
+int64_t ttvk_vq_workspace_bytes(int rows);
+int ttvk_vq_l2_argmin(const void* z, int dtype, int ldz, const void* cb, int ldc, const float* cnorm, int rows, int N, int C, int* indices,
+                      float* best_dist, void* workspace, int64_t workspace_bytes, hipStream_t s);
+int ttvk_vq_lookup(const void* cb, int dtype, int ldc, const int* indices, int rows, int C, void* codes, int ldo, hipStream_t s);
+
 // ---- ttv_mlp.hip ----
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner);
 struct MlpNextQkv {     // optional fused back of the layer-tail kernel: the next layer's qkv projection + rotary

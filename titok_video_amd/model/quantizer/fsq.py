@@ -48,6 +48,12 @@ class FSQ(nn.Module):
         hw = _levels // 2
         self.register_buffer("implicit_codebook", (lvl - hw) / hw, persistent=False)
 
+    def lattice_codebook(self) -> torch.Tensor:
+        """fp32 [codebook_size, C]: the implicit codebook in LATTICE units, implicit_codebook * (levels // 2) (fsq.py:73-76, 89).
+        The entry nearest (L2) to `bounded(z)` is FSQ's own index away from rounding ties - the codebook on which
+        quantizer.vq_l2.L2Quantizer reproduces this module."""
+        return (self.implicit_codebook * (self._levels // 2).to(torch.float32)).contiguous()
+
     # -- hot path ---------------------------------------------------------------------------------
     def _run(self, z: torch.Tensor, want_bounded: bool):
         _lib.require_gpu(z, "FSQ.forward")
