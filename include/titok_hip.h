@@ -366,6 +366,13 @@ int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int c
 int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, const int32_t* sizes, int n_clips, int dtype, float* loss,
                 void* stream);
 
+/* PSNR statistic of the evaluation loop (model/metrics/eval_metrics.py:19,32-36: x.clamp(-1, 1), torchmetrics
+ * PeakSignalNoiseRatio(data_range=2) = running sum of squared errors + element count): acc[0] += sum (clamp(recon) - target)^2,
+ * acc[1] += number of elements, both double, device memory, over the clips of the call (host arrays of device pointers, `dtype`).
+ * PSNR = 10 log10(4 * acc[1] / acc[0]) is finished on the host (one read when the score is wanted, none per step). */
+int ttv_sq_err_accumulate(void* const* recon, void* const* target, const int32_t* sizes, int n_clips, int dtype, int clamp, double* acc,
+                          void* stream);
+
 /* ---- measurement hook (bench.py roofline leg) ---------------------------------------------------------- */
 /* Kernel classes whose launches can be bracketed by HIP events on the stream they are launched on. */
 #define TTV_KC_ATTENTION 1

@@ -462,3 +462,26 @@ def test_errors_are_loud():
     x = torch.zeros(4, 100, device=DEV)
     with pytest.raises(RuntimeError, match="K="):
         _lib.check(L().ttv_linear(x.data_ptr(), 100, x.data_ptr(), 100, None, None, x.data_ptr(), 4, 4, 4, 98, _lib.TTV_F32, S()), "linear")
+
+
+# ---------------------------------------------------------------------------------------------- PSNR statistic
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_psnr_matches_the_reference_definition(dtype):
+    """EvalMetrics (reference model/metrics/eval_metrics.py:19,32-36): x.clamp(-1, 1), PSNR with data_range 2 over ALL elements of all
+    updates = 10 log10(4 / MSE); fused squared-error reduction against float64 on the host, ragged clip shapes, two updates."""
+    from titok_video_amd.model.metrics.eval_metrics import EvalMetrics
+    g = torch.Generator().manual_seed(4)
+    shapes = [(3, 4, 16, 24), (3, 8, 8, 8), (3, 4, 40, 8), (3, 2, 5, 7)]
+    target = [(torch.rand(s, generator=g) * 2 - 1).to(dtype) for s in shapes]
+    recon = [(t.float() + 0.3 * torch.randn(t.shape, generator=g)).to(dtype) for t in target]      # some values leave [-1, 1]: clamped
+    m = EvalMetrics()
+    m.update([r.to(DEV) for r in recon[:3]], [t.to(DEV) for t in target[:3]])
+    m.update([recon[3].to(DEV)], [target[3].to(DEV)])
+    got = m.compute()["eval/psnr"]
+    sq = sum(float(((r.double().clamp(-1, 1) - t.double()) ** 2).sum()) for r, t in zip(recon, target))
+    n = sum(t.numel() for t in target)
+    ref = 10.0 * np.log10(4.0 * n / sq)
+    assert abs(got - ref) < (1e-4 if dtype == torch.float32 else 1e-3), (got, ref)
+    m.reset()
+    m.update([target[0].to(DEV)], [target[0].to(DEV)])
+    assert m.compute()["eval/psnr"] == float("inf")

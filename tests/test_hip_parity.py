@@ -542,3 +542,55 @@ def test_weight_updates_through_data_reach_the_kernels():
         fresh.load_state_dict(model.state_dict(), strict=True)
         r4, o4 = fresh(clips, counts)
         assert torch.equal(o3["indices"], o4["indices"]) and torch.equal(r3[0], r4[0])
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config #4
+def _base_setup(dtype):
+    d = np.load(os.path.join(G, "titok_base_cfg4.npz"))
+    levels = d["levels"].tolist()
+    m = TiTok(config(levels=levels, enc="base", dec="base"))
+    m.load_state_dict(seeded_titok_state(int(d["weight_seed"]), "base", "base", gain=float(d["weight_gain"])), strict=True)
+    m = m.to(DEV, dtype).eval()
+    shape, count = tuple(d["shape"].tolist()), int(d["count"])
+    clips = synthetic_clips([shape], seed=int(d["clip_seed"]), dtype=dtype, device=DEV)
+    return d, levels, m, shape, count, clips
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "titok_base_cfg4.npz")), reason="fixture not generated")
+def test_base_cfg4_fp32_vs_reference():
+    """BASELINE config #4 at its real size: base towers (d = 768, 12 layers, heads 12/4), ONE 32x256x256 clip, K = 1024 latent tokens -
+    a 9216-row sequence (144 key tiles, 72 query blocks per head), FSQ [8,8,8,6,5] - against the reference's own fp32 run
+    (tests/golden/make_golden_base.py).  float32 towers: the reference's index on every token away from a rounding boundary."""
+    d, levels, m, shape, count, clips = _base_setup(torch.float32)
+    with torch.no_grad():
+        codes, od = m.encode(clips, [count], want_bounded=True)
+        recon = m.decode(codes, [count], [shape])
+    idx = od["indices"].cpu().numpy()
+    margin = O.fsq_margin(torch.from_numpy(d["bounded"])).numpy()
+    safe = margin > TAU_F32
+    print(f"base cfg4 fp32: {int((idx != d['indices']).sum())} of {idx.size} indices differ; {int(safe.sum())} tokens with margin > {TAU_F32}; "
+          f"max |bounded err| {float(np.abs(m.last_bounded.cpu().numpy() - d['bounded']).max()):.2e}")
+    assert np.array_equal(idx[safe], d["indices"][safe])
+    assert (idx != d["indices"]).sum() <= 3
+    np.testing.assert_allclose(m.last_bounded.cpu().numpy(), d["bounded"], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(recon[0].cpu().numpy()[:, ::4, ::8, ::8], d["recon_sample"], rtol=0, atol=2e-2)
+    assert abs(float(recon[0].double().std()) - float(d["recon_std"])) < 2e-3
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "titok_base_cfg4.npz")), reason="fixture not generated")
+def test_base_cfg4_bf16_vs_reference():
+    """The same clip through the bf16 kernels (general-K GEMMs at widths 768 / 2048, the attention kernel at 12/4 heads and 144 key
+    tiles): not worse than the reference's own bf16 run (fixture keys *_refbf16), fixed thresholds as for the tiny fixtures."""
+    d, levels, m, shape, count, clips = _base_setup(torch.bfloat16)
+    with torch.no_grad():
+        codes, od = m.encode(clips, [count], want_bounded=True)
+    assert_bf16_not_worse_than_yardstick("base cfg4", od["indices"].cpu().numpy(), m.last_bounded.cpu(), d["indices"], torch.from_numpy(d["bounded"]),
+                                         d["indices_refbf16"], torch.from_numpy(d["bounded_refbf16"]))
+    ref_codes = O.fsq_indices_to_codes(torch.from_numpy(d["indices"]), levels).to(torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        rec = m.decode(ref_codes, [count], [shape])
+    mine = rec[0].float().cpu()[:, ::4, ::8, ::8].flatten()
+    ref, ref16 = torch.from_numpy(d["recon_sample"]).flatten(), torch.from_numpy(d["recon_sample_refbf16"]).flatten()
+    e_mine, e_ref16 = float((mine - ref).norm() / ref.norm()), float((ref16 - ref).norm() / ref.norm())
+    print(f"   decoder rel. error vs fp32 reference: HIP {e_mine:.5f} | reference-in-bf16 {e_ref16:.5f}")
+    assert e_mine <= 1.15 * e_ref16 + 1e-3

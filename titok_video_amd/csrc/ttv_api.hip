@@ -438,6 +438,15 @@ int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, cons
   return TTV_OK;
 }
 
+int ttv_sq_err_accumulate(void* const* recon, void* const* target, const int32_t* sizes, int n_clips, int dtype, int clamp, double* acc,
+                          void* stream) {
+  for (int c0 = 0; c0 < n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {
+    const int n = n_clips - c0 < TTV_MAX_CLIPS_PER_LAUNCH ? n_clips - c0 : TTV_MAX_CLIPS_PER_LAUNCH;
+    TTV_TRY(ttvk_sq_err(recon + c0, target + c0, sizes + c0, n, dtype, clamp, acc, (hipStream_t)stream));
+  }
+  return TTV_OK;
+}
+
 int ttv_debug_set(int flags) {
   g_ttv_debug = flags;
   return TTV_OK;

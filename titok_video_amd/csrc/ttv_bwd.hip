@@ -1525,6 +1525,65 @@ __global__ __launch_bounds__(256) void k_l1_loss(L1Clips c, float inv_clips, flo
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * w);
 }
 
+// Squared error of clamp(recon, -1, 1) against target, summed over the clips of a call into a double accumulator (the statistic
+// behind the reference's PSNR: model/metrics/eval_metrics.py:19,32-36 = torchmetrics PeakSignalNoiseRatio(data_range=2), which keeps
+// the running sum of squared errors and the element count over all update() calls).  acc[0] += sum (clamp(r) - t)^2, acc[1] += count.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sq_err(L1Clips c, int clamp, double* __restrict__ acc2) {
+  __shared__ float red[4];
+  const int ci = blockIdx.y, n = c.n[ci];
+  const T* r = reinterpret_cast<const T*>(c.recon[ci]);
+  const T* t = reinterpret_cast<const T*>(c.target[ci]);
+  float acc = 0.f;
+  constexpr int V = 16 / (int)sizeof(T);
+  const bool vec_ok = (((uintptr_t)r | (uintptr_t)t) & 15) == 0;
+  const int nv = vec_ok ? n / V : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
+    T rv[V], tv[V];
+    *reinterpret_cast<uint4*>(rv) = reinterpret_cast<const uint4*>(r)[i];
+    *reinterpret_cast<uint4*>(tv) = reinterpret_cast<const uint4*>(t)[i];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float x = (float)rv[e];
+      if (clamp) x = __builtin_amdgcn_fmed3f(x, -1.0f, 1.0f);
+      const float d = x - (float)tv[e];
+      acc = fmaf(d, d, acc);
+    }
+  }
+  for (int i = nv * V + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float x = (float)r[i];
+    if (clamp) x = __builtin_amdgcn_fmed3f(x, -1.0f, 1.0f);
+    const float d = x - (float)t[i];
+    acc = fmaf(d, d, acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc2[0], (double)(red[0] + red[1] + red[2] + red[3]));
+    if (blockIdx.x == 0) atomicAdd(&acc2[1], (double)n);
+  }
+}
+
+int ttvk_sq_err(void* const* recon, void* const* target, const int* sizes, int n_clips, int dtype, int clamp, double* acc2, hipStream_t s) {
+  TTV_CHECK_ARG(n_clips >= 0 && n_clips <= TTV_MAX_CLIPS_PER_LAUNCH, "sq_err: at most %d clips per call", TTV_MAX_CLIPS_PER_LAUNCH);
+  if (n_clips == 0) return TTV_OK;
+  TTV_CHECK_ARG(recon && target && sizes && acc2, "sq_err: null argument");
+  L1Clips c;
+  int mx = 0;
+  for (int i = 0; i < n_clips; ++i) {
+    c.recon[i] = recon[i]; c.target[i] = target[i]; c.grad[i] = nullptr; c.n[i] = sizes[i];
+    TTV_CHECK_ARG(sizes[i] > 0 && recon[i] && target[i], "sq_err: empty clip");
+    mx = sizes[i] > mx ? sizes[i] : mx;
+  }
+  int bx = ttv_cdiv(mx, 256 * 8);
+  bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_sq_err<bf16_t>), dim3(bx, n_clips), dim3(256), 0, s, c, clamp, acc2);
+  else hipLaunchKernelGGL((k_sq_err<float>), dim3(bx, n_clips), dim3(256), 0, s, c, clamp, acc2);
+  TTV_CHECK_LAUNCH("sq_err");
+  return TTV_OK;
+}
+
 int ttvk_l1_loss(void* const* recon, void* const* target, void* const* grad, const int* sizes, int n_clips, int total_clips, int dtype,
                  float* loss, hipStream_t s) {
   TTV_CHECK_ARG(n_clips >= 0 && n_clips <= TTV_MAX_CLIPS_PER_LAUNCH && total_clips >= n_clips, "l1_loss: at most %d clips per call", TTV_MAX_CLIPS_PER_LAUNCH);

@@ -20,6 +20,8 @@
 //   k_gemm_bf16 : general K: 128 features x 128 tokens x 64 K tiles, 4 waves (2x2), register-staged double-buffered
 //                 LDS, XOR-swizzled 16-byte chunks (conflict-free ds_read_b128), XCD-aware tile order.
 //   k_gemm_f32  : fp32 towers (bit-exact token indices): exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), 128x128x32 tiles.
+#include <stdlib.h>
+
 #include "ttv_common.h"
 #include "ttv_kernels.h"
 
@@ -356,6 +358,128 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GemmDev p, int n_ftiles) {
 #undef GXPTR
 #undef LDSW
 #undef LDSX
+
+  int tok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
+  if (DUAL) {
+    int feat[2];
+    f32x4 ax[2][NJ], ag[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
+    }
+    epilogue_tile<EPI, bf16_t, 2, NJ>(p, tok, feat, ax, ag, kq);
+  } else {
+    int feat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
+    epilogue_tile<EPI, bf16_t, 4, NJ>(p, tok, feat, acc, acc, kq);
+  }
+}
+
+// ================================================================================================
+// The same 128-feature x 128/160-token x 64-K structure with both operand tiles staged by LDS-DMA (global_load_lds_dwordx4) instead
+// of through registers: no staging VGPRs, no ds_write pass, the next k-tile's loads are issued right after the barrier and land
+// behind the whole MFMA phase.  One wave-instruction fills 1 KiB = 8 tile rows of 128 bytes, lane-linear in LDS, so the XOR
+// swizzle of the fragment reads is applied on the SOURCE side (lane l of an instruction fetches chunk (l & 7) ^ ((row >> 1) & 7)
+// of row l >> 3); the k-tile is a scalar base, the lane's share of it constant byte offsets (clamped rows included).
+// Used when K % 64 == 0 and the operands fit 32-bit byte offsets (every linear of the base / large towers); the register-staged
+// kernel above keeps the other cases (patch gather, K tails).
+// ================================================================================================
+template <int EPI, int NJ>
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16_dma(GemmDev p, int n_ftiles) {
+  constexpr bool DUAL = (EPI == EPI_GEGLU);
+  constexpr int FT = DUAL ? 64 : TF;
+  constexpr int TTK = 32 * NJ;
+  constexpr int XI = TTK / 32;                  // X DMA instructions per wave and k-tile (8 rows each): 4 or 5
+  __shared__ __attribute__((aligned(16))) uint4 lds[2][(TF + TTK) * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wave & 1, wt = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int fbase = (tile % n_ftiles) * FT;
+  const int tbase = (tile / n_ftiles) * TTK;
+  const bf16_t* W = (const bf16_t*)p.w;
+  const bf16_t* X = (const bf16_t*)p.x;
+
+  // lane-constant source byte offsets: W instruction i of this wave covers tile rows 32 wave + 8 i + (lane >> 3)
+  const int lr = lane >> 3, lp = lane & 7;
+  uint32_t woff[4], xoff[XI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lr;
+    int wr;
+    if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
+    else wr = fbase + row;
+    wr = wr < p.w_rows ? wr : p.w_rows - 1;
+    woff[i] = ((uint32_t)wr * (uint32_t)p.ldw + (uint32_t)((lp ^ ((row >> 1) & 7)) * 8)) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = wave * (8 * XI) + i * 8 + lr;
+    int xr = tbase + row;
+    xr = xr < p.M ? xr : p.M - 1;
+    xoff[i] = ((uint32_t)xr * (uint32_t)p.ldx + (uint32_t)((lp ^ ((row >> 1) & 7)) * 8)) * 2u;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&lds[0][0];
+  constexpr uint32_t BUFB = (TF + TTK) * 128;   // bytes per buffer
+#define GD_DMA(voff_, base_, dst_)                                                                               \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                 \
+  } while (0)
+#define GD_STAGE(kt_, buf_)                                                                                      \
+  do {                                                                                                           \
+    const bf16_t* wb__ = W + (size_t)(kt_) * BK;                                                                 \
+    const bf16_t* xb__ = X + (size_t)(kt_) * BK;                                                                 \
+    const uint32_t dw__ = lds0 + (buf_) * BUFB + wave * 4096;                                                    \
+    const uint32_t dx__ = lds0 + (buf_) * BUFB + TF * 128 + wave * (1024 * XI);                                  \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) GD_DMA(woff[i__], wb__, dw__ + i__ * 1024);              \
+    _Pragma("unroll") for (int i__ = 0; i__ < XI; ++i__) GD_DMA(xoff[i__], xb__, dx__ + i__ * 1024);             \
+  } while (0)
+
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nk = p.K / BK;
+  GD_STAGE(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) GD_STAGE(kt + 1, buf ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[NJ];
+      const int kc = ks * 4 + kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+        a[i] = __builtin_bit_cast(bf16x8, lds[buf][arow * 8 + (kc ^ ((arow >> 1) & 7))]);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int brow = wt * (16 * NJ) + j * 16 + l15;
+        b[j] = __builtin_bit_cast(bf16x8, lds[buf][TF * 8 + brow * 8 + (kc ^ ((brow >> 1) & 7))]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next k-tile has landed
+    __syncthreads();
+  }
+#undef GD_STAGE
+#undef GD_DMA
 
   int tok[NJ];
 #pragma unroll
@@ -999,10 +1123,16 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     // rounds of 512 resident blocks x tile height: the 160-token tile when it saves a (mostly empty) round
     const int force_tt = (d.debug & 128) ? 160 : (d.debug & 256) ? 128 : 0;   // diagnostics / tests (ttv_debug_set)
     const long cost128 = (long)ttv_cdiv(nf * nt, 512) * 128, cost160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
-    if ((cost160 < cost128 && force_tt != 128) || force_tt == 160)
-      hipLaunchKernelGGL((k_gemm_bf16<EPI, false, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
-    else
-      hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    // both tiles by LDS-DMA when the k range is whole 64-element tiles and a lane's byte offset fits 32 bits (TTV_GEMM_DMA=0: A/B)
+    static const bool use_dma = !(getenv("TTV_GEMM_DMA") && getenv("TTV_GEMM_DMA")[0] == '0');
+    const bool dma_ok = use_dma && d.K % BK == 0 && (uint64_t)d.M * (uint64_t)d.ldx * 2u < (1ull << 32) && (uint64_t)d.w_rows * (uint64_t)d.ldw * 2u < (1ull << 32);
+    if ((cost160 < cost128 && force_tt != 128) || force_tt == 160) {
+      if (dma_ok) hipLaunchKernelGGL((k_gemm_bf16_dma<EPI, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+      else hipLaunchKernelGGL((k_gemm_bf16<EPI, false, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+    } else {
+      if (dma_ok) hipLaunchKernelGGL((k_gemm_bf16_dma<EPI, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+      else hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    }
   } else {
     const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT);
     hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);

@@ -96,6 +96,7 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
 // ---- ttv_bwd.hip (backward kernels) ----
 int ttvk_l1_loss(void* const* recon, void* const* target, void* const* grad, const int* sizes, int n_clips, int total_clips, int dtype,
                  float* loss, hipStream_t s);
+int ttvk_sq_err(void* const* recon, void* const* target, const int* sizes, int n_clips, int dtype, int clamp, double* acc2, hipStream_t s);
 // dx (fp32, in/out) = out_scale * B(A), cast_out = (T) B(A) with A = dx + rmsnorm_bwd(x, gain1, dy), B = rmsnorm_bwd(y, gain2, .) or
 // identity when y == NULL; gain gradients accumulated with atomics (dgain1 / dgain2 may be NULL); cast_out may be NULL
 int ttvk_rmsnorm_bwd_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
