@@ -297,6 +297,11 @@ typedef struct ttv_tower_grads {
   float* proj_in_w; float* proj_in_b; float* mask_token; float* ln_pre_t; float* ln_pre_p; float* ln_post; float* proj_out_w;
   float* proj_out_b;
   const ttv_layer_grads* layers;       /* HOST array [layers] */
+  /* optional HOST array [layers] of hipEvent_t (created by the caller): event i is recorded on `stream` right after the last kernel
+   * that writes layer i's gradients (the backward visits the layers top down, so these complete in the order layers-1 .. 0).  A
+   * data-parallel caller makes its communication stream wait for event i and all-reduces layer i's gradient slice while the
+   * backward of the layers below is still running (reference step: train.py:75-83).  NULL = no events. */
+  void** layer_done_events;
 } ttv_tower_grads;
 
 int64_t ttv_tower_tape_bytes(const ttv_tower_dims* dims, const ttv_batch* batch);

@@ -69,3 +69,83 @@ def test_two_rank_training_step_equals_single_process():
         for n, v in params.items():
             err = float((torch.from_numpy(v) - ref[n]).norm() / (ref[n].norm() + 1e-30))
             assert err < 1e-5, (rank, n, err)
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from titok_video_amd import dp
+        from titok_video_amd.synthetic import synthetic_clips
+        from titok_video_amd.train import make_optimizer, training_step
+        all_clips = synthetic_clips(SHAPES, seed=77, dtype=torch.float32, device="cuda:0")
+        mine = dp.shard_clips(len(SHAPES), rank, world)
+        out = {}
+        for overlap in (False, True):
+            model = _model()
+            opt = make_optimizer(model)
+            # gradients only: clip / step afterwards would hide nothing but make the comparison about the optimizer
+            opt.zero_grad(set_to_none=True)
+            from titok_video_amd.train import _reducer_for, _towers, l1_reconstruction_loss
+            red = _reducer_for(model, None, overlap)
+            if red is not None:
+                red.attach(*_towers(model))
+                red.begin_step(len(mine))
+            clips = [all_clips[i] for i in mine]
+            recon, info = model(clips, [COUNTS[i] for i in mine])
+            l1_reconstruction_loss(recon, clips).backward()
+            params = [p for p in model.parameters() if p.grad is not None]
+            if red is not None:
+                red.detach(*_towers(model))
+                red.finish()
+                assert red.slices == 2 * (4 + 1)            # per tower: one slice per layer + the head / tail block
+            else:
+                dp.allreduce_mean_by_count([p.grad for p in params], len(mine))
+            torch.cuda.synchronize()
+            out[overlap] = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+        # the reduction arithmetic alone, on the SAME local buffer: slices through the reducer vs one bucket through the sequential path
+        g = torch.Generator().manual_seed(50 + rank)
+        local = torch.randn(100_003, generator=g).to("cuda:0")
+        a, b = local.clone(), local.clone()
+        red = dp.GradReducer(torch.device("cuda:0"))
+        red.begin_step(rank + 1)
+        ev = torch.cuda.Event()
+        ev.record()
+        for lo, hi in ((60_000, 100_003), (0, 60_000)):
+            red.reduce_slice(a, lo, hi, ev)
+        red.finish()
+        dp.allreduce_mean_by_count([b], rank + 1)
+        torch.cuda.synchronize()
+        out["arith_equal"] = bool(torch.equal(a, b))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_reduction_equals_the_sequential_one_bit_for_bit():
+    """dp.GradReducer (layer slices reduced in place from the flat buffer, behind the backward) against dp.allreduce_mean_by_count
+    (after the backward, concatenated buckets): the same multiply - sum over ranks - divide per element, so bit-identical fp32
+    weight gradients on both ranks (vector parameters carry the backward's own atomic-order noise), ragged clip counts (2 + 1)."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out.pop("arith_equal")                        # same buffer in, bit-identical out: multiply - sum over ranks - divide
+        assert set(out[False]) == set(out[True]) and len(out[True]) == 76
+        for n in out[False]:
+            # two separate fp32 backward runs: the float32 gradient kernels accumulate with atomics (run-to-run last-bit noise), so
+            # the end-to-end comparison carries that noise; the reduction itself is checked bit for bit above
+            scale = float(np.abs(out[False][n]).max()) + 1e-12
+            assert float(np.abs(out[False][n] - out[True][n]).max()) < 1e-4 * scale, (rank, n)
+    # and both ranks hold the same reduced gradients
+    for n in res[0][1][True]:
+        assert np.array_equal(res[0][1][True][n], res[1][1][True][n]), n       # an all-reduce leaves the same bits on every rank

@@ -72,7 +72,7 @@ class LayerGrads(C.Structure):
 
 class TowerGrads(C.Structure):
     _fields_ = [("proj_in_w", vp), ("proj_in_b", vp), ("mask_token", vp), ("ln_pre_t", vp), ("ln_pre_p", vp), ("ln_post", vp),
-                ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerGrads))]
+                ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerGrads)), ("layer_done_events", C.POINTER(vp))]
 
 
 _lib = None

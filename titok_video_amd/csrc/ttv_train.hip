@@ -221,6 +221,13 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
                                      post ? w->layers[i - 1].ffd_post_ln : nullptr, post ? gr->layers[i - 1].ffd_post_ln : nullptr,
                                      post ? d->alpha : 1.f, ws.g_d, dm, L, dm, d->eps, dt, s));
     }
+    // every gradient of layer i is final here (its ffd_post_ln gain received its contribution in the iteration above)
+    if (gr->layer_done_events && gr->layer_done_events[i]) {
+      if (hipEventRecord((hipEvent_t)gr->layer_done_events[i], s) != hipSuccess) {
+        ttv_set_error("backward: hipEventRecord(layer_done_events[%d]) failed", i);
+        return TTV_ERR_LAUNCH;
+      }
+    }
   }
   return TTV_OK;
 }

@@ -44,6 +44,97 @@ def gather_variable(t: torch.Tensor, group=None) -> List[torch.Tensor]:
     return [o[: int(s)] for o, s in zip(outs, sizes)]
 
 
+class GradReducer:
+    """Count-weighted gradient all-reduce OVERLAPPED with the backward pass (the exchange step of the reference's training step,
+    train.py:75-83, as BASELINE.json's north_star states it: "RCCL all-reduce of grads ... overlapped with backward").
+
+    The towers' hand-written backward writes every parameter gradient into ONE flat fp32 buffer per tower in which a layer's
+    gradients are contiguous, and records an event per layer as soon as that layer's slice is final (ttv_tower_grads.
+    layer_done_events; the backward visits the layers top down).  `reduce_slice` is called by the tower's autograd function right
+    after the backward kernels have been ENQUEUED: a communication stream waits for the slice's event, multiplies the slice by
+    this rank's clip count, all-reduces it in place (RCCL over xGMI: one message per layer slice, 3-30 MB - ring collectives are
+    bound per link, so fewer / larger messages; no concatenation, no copy) and divides by the global count, while the compute
+    stream goes on with the layers below and the next tower.  The result is sum_r(count_r * grad_r) / sum_r(count_r): the
+    single-process mean over the union batch also when ranks hold different numbers of clips.
+
+    The global clip count is exchanged at `begin_step` (one 8-byte all-reduce on the communication stream, long finished when the
+    first slice arrives) and stays on the device: no host synchronisation anywhere between backward and the optimizer step.
+    `finish()` makes the current stream wait for the communication stream (call it before clipping / the optimizer).
+
+    backend "gloo" (CPU-side collective; the tests' stand-in for RCCL, both ranks on one GPU): same arithmetic, the slice is
+    staged through the host - which synchronises, so nothing overlaps there; the results are bit-identical to RCCL's order of
+    operations (multiply, sum over ranks, divide) and to `allreduce_mean_by_count`."""
+
+    def __init__(self, device, group=None):
+        self.device = torch.device(device)
+        self.group = group
+        self.rank, self.world = world()
+        self.gloo = self.world > 1 and dist.get_backend(group) == "gloo"
+        self.comm = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._local = None      # fp32 device scalar: this rank's clip count
+        self._total = None      # fp32 device scalar: the global clip count
+        self.bytes_reduced = 0
+        self.slices = 0
+
+    def attach(self, *towers) -> None:
+        for t in towers:
+            t._grad_reducer = self
+
+    def detach(self, *towers) -> None:
+        for t in towers:
+            t.__dict__.pop("_grad_reducer", None)
+
+    def begin_step(self, local_count: int) -> None:
+        self.bytes_reduced, self.slices = 0, 0
+        if self.world == 1:
+            return
+        if self.gloo:
+            cnt = torch.tensor([float(local_count)], dtype=torch.float64)
+            dist.all_reduce(cnt, group=self.group)
+            self._local = torch.tensor(float(local_count), dtype=torch.float32, device=self.device)
+            self._total = torch.tensor(float(cnt.item()), dtype=torch.float32, device=self.device)
+            return
+        self.comm.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.comm):
+            self._local = torch.full((), float(local_count), dtype=torch.float32, device=self.device)
+            tot = self._local.clone()
+            dist.all_reduce(tot, group=self.group)
+            self._total = tot
+
+    def reduce_slice(self, flat: torch.Tensor, lo: int, hi: int, ready: "torch.cuda.Event") -> None:
+        """In place on flat[lo:hi] (fp32), after `ready`, on the communication stream."""
+        if self.world == 1 or hi <= lo:
+            return
+        sl = flat[lo:hi]
+        self.bytes_reduced += 4 * (hi - lo)
+        self.slices += 1
+        if self.gloo:
+            ready.synchronize()
+            host = (sl * self._local).cpu()
+            dist.all_reduce(host, group=self.group)
+            sl.copy_(host.to(sl.device))
+            sl.div_(self._total)
+            return
+        self.comm.wait_event(ready)
+        with torch.cuda.stream(self.comm):
+            sl.mul_(self._local)
+            dist.all_reduce(sl, group=self.group)
+            sl.div_(self._total)
+        flat.record_stream(self.comm)
+
+    def stream(self):
+        """Context in which a tower turns its reduced flat buffer into per-parameter gradients (casts / permutations run behind
+        the reductions on the communication stream instead of making the compute stream wait for them)."""
+        import contextlib
+        if self.world == 1 or self.gloo or self.comm is None:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.comm)
+
+    def finish(self) -> None:
+        if self.world > 1 and not self.gloo and self.comm is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm)
+
+
 def allreduce_mean_by_count(grads: Iterable[torch.Tensor], local_count: int, group=None, bucket_bytes: int = 64 << 20) -> int:
     """In-place: grads <- sum_over_ranks(local_count * grads) / sum_over_ranks(local_count).
 
@@ -64,14 +155,17 @@ def allreduce_mean_by_count(grads: Iterable[torch.Tensor], local_count: int, gro
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([g.reshape(-1).to(torch.float32) for g in bucket]) * float(local_count)
+        # element-wise: (count * g) summed over ranks, then a true fp32 division by the total - written with tensor operands so that
+        # it is the same arithmetic as GradReducer's device-side scalars (torch turns `x / python_float` into `x * (1 / float)`)
+        flat = torch.cat([g.reshape(-1).to(torch.float32) for g in bucket])
+        flat = flat * torch.tensor(float(local_count), dtype=torch.float32, device=flat.device)
         if flat.is_cuda and dist.get_backend(group) == "gloo":     # CPU-side collective (tests); RCCL reduces in place on the GPU
             host = flat.cpu()
             dist.all_reduce(host, group=group)
             flat = host.to(flat.device)
         else:
             dist.all_reduce(flat, group=group)
-        flat /= total
+        flat = flat / torch.tensor(total, dtype=torch.float32, device=flat.device)
         off = 0
         for g in bucket:
             n = g.numel()

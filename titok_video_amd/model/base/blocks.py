@@ -223,7 +223,48 @@ class _Tower(nn.Module):
                 k += 2
         st = _lib.TowerGrads(proj_in_w=ptr[0], proj_in_b=ptr[1], mask_token=ptr[2], ln_pre_t=ptr[3], ln_pre_p=ptr[4], ln_post=ptr[5],
                              proj_out_w=ptr[6], proj_out_b=ptr[7], layers=lay)
+        # data-parallel training (dp.GradReducer attached): one event per layer, recorded by the library when the layer's slice is final
+        events = None
+        if self.__dict__.get("_grad_reducer") is not None and flat.is_cuda:
+            events = [torch.cuda.Event() for _ in range(self.num_layers)]
+            cur = torch.cuda.current_stream(flat.device)
+            for e in events:
+                e.record(cur)                      # creates the underlying hipEvent (lazy in torch) so that its handle can be passed
+            arr = (_lib.vp * self.num_layers)(*[e.cuda_event for e in events])
+            st.layer_done_events = arr
+            lay = (lay, arr)                       # keep the ctypes arrays alive with the struct
+        self.__dict__["_last_grad_events"] = events
         return flat, st, lay
+
+    def _reduce_and_finish(self, flat: torch.Tensor):
+        """After the backward kernels are enqueued: hand the flat gradient buffer to the attached dp.GradReducer slice by slice
+        (layer slices in the order the backward completes them, then the head / tail parameters, which are final only at the end of
+        the backward), and build the per-parameter gradients behind the reductions."""
+        red = self.__dict__.get("_grad_reducer")
+        events = self.__dict__.pop("_last_grad_events", None)
+        if red is None or events is None:
+            return self._finish_grads(flat)
+        _params, _shapes, sizes, offs, tot = self._grad_layout()
+        bounds = []                                    # [lo, hi) of every layer in the flat buffer (entries 8.. of the layout)
+        k = 8
+        for i in range(self.num_layers):
+            n_i = 6 if i == 0 else 8
+            lo = offs[k]
+            hi = offs[k + n_i] if k + n_i < len(offs) else tot
+            bounds.append((lo, hi))
+            k += n_i
+        for i in reversed(range(self.num_layers)):
+            red.reduce_slice(flat, bounds[i][0], bounds[i][1], events[i])
+        tail = torch.cuda.Event()
+        tail.record(torch.cuda.current_stream(flat.device))
+        red.reduce_slice(flat, 0, offs[8], tail)       # proj_in / mask_token / ln_pre / ln_post / proj_out
+        with red.stream():
+            out = self._finish_grads(flat)
+        if red.comm is not None and red.world > 1 and not red.gloo:
+            cur = torch.cuda.current_stream(flat.device)
+            for g in out.values():
+                g.record_stream(cur)               # produced on the communication stream, consumed on the compute stream after finish()
+        return out
 
     def _finish_grads(self, flat: torch.Tensor):
         """Flat packed fp32 gradients -> {id(parameter): gradient in the reference layout and the parameter's dtype}: one cast of
@@ -548,7 +589,7 @@ class _EncoderTrainFn(torch.autograd.Function):
                                       dz.contiguous().float().data_ptr(), ctx.tape.data_ptr(), None if frozen else C.byref(gstruct),
                                       _lib.ptr_array(dclips) if dclips else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_encoder_backward")
-        by_id = {} if frozen else tower._finish_grads(flat)
+        by_id = {} if frozen else tower._reduce_and_finish(flat)
         clip_grads = [dclips[i] if (dclips and ctx.clip_grad[i]) else None for i in range(ctx.n_clips)]
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None
@@ -589,7 +630,7 @@ class _DecoderTrainFn(torch.autograd.Function):
                                       ctx.tokens.data_ptr(), _lib.ptr_array(dcl), ctx.tape.data_ptr(), C.byref(gstruct),
                                       dcodes.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
         _lib.check(rc, "ttv_decoder_backward")
-        by_id = tower._finish_grads(flat)
+        by_id = tower._reduce_and_finish(flat)
         param_grads = [by_id.get(id(p)) if p.requires_grad else None for p in ctx.params]
         ctx.tape = None
         return (None, None, None, dcodes.to(ctx.tokens.dtype) if ctx.tokens_grad else None, *param_grads)

@@ -67,15 +67,52 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, beta1: float = 0.5,
     return torch.optim.AdamW(params, lr=lr, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused)
 
 
+def _reducer_for(model, group, overlap: bool):
+    """The dp.GradReducer of a model's towers (created on first use, cached on the model) when torch.distributed is active and the
+    gradients live on a GPU; None otherwise (single process, or `overlap=False`: the sequential reference path)."""
+    rank, ws = dp.world()
+    if ws == 1 or not overlap:
+        return None
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        return None
+    red = model.__dict__.get("_dp_reducer")
+    if red is None or red.group is not group:
+        red = dp.GradReducer(dev, group)
+        model.__dict__["_dp_reducer"] = red
+    return red
+
+
+def _towers(*modules):
+    from .model.base.blocks import _Tower
+    return [m for mod in modules for m in mod.modules() if isinstance(m, _Tower)]
+
+
 def training_step(model, clips: List[torch.Tensor], token_counts, optimizer, max_grad_norm: float = 1.0,
-                  target: Optional[List[torch.Tensor]] = None, group=None):
-    """One generator step on this rank's clips.  Returns (loss, grad_norm, indices)."""
+                  target: Optional[List[torch.Tensor]] = None, group=None, overlap: bool = True):
+    """One generator step on this rank's clips.  Returns (loss, grad_norm, indices).
+
+    Under torch.distributed the gradients are reduced as sum(count * grad) / sum(count).  overlap=True (default): layer by layer
+    on a communication stream while the backward is still running (dp.GradReducer); overlap=False: after the backward, in flat
+    buckets (dp.allreduce_mean_by_count) - same values, kept as the reference for the overlapped path."""
     optimizer.zero_grad(set_to_none=True)
-    recon, out = model(clips, token_counts)
-    loss = l1_reconstruction_loss(recon, target if target is not None else clips)
-    loss.backward()
+    red = _reducer_for(model, group, overlap)
+    towers = _towers(model) if red is not None else []
+    if red is not None:
+        red.attach(*towers)
+        red.begin_step(len(clips))
+    try:
+        recon, out = model(clips, token_counts)
+        loss = l1_reconstruction_loss(recon, target if target is not None else clips)
+        loss.backward()
+    finally:
+        if red is not None:
+            red.detach(*towers)
     params = [p for p in model.parameters() if p.grad is not None]
-    dp.allreduce_mean_by_count([p.grad for p in params], len(clips), group=group)
+    if red is not None:
+        red.finish()
+    else:
+        dp.allreduce_mean_by_count([p.grad for p in params], len(clips), group=group)
     gnorm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     optimizer.step()
     return loss.detach(), gnorm, out["indices"]
@@ -90,31 +127,55 @@ def make_discriminator_optimizer(loss_module: torch.nn.Module, lr: float = 1e-4,
 
 
 def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_counts, opt_g, opt_d=None, max_grad_norm: float = 1.0,
-                      group=None):
+                      group=None, overlap: bool = True):
     """One generator step followed by one discriminator step on this rank's clips (reference train.py:64-107).
 
     generator:      recon = model(clips); loss = loss_module(target=clips, recon=recon)  [L1 + disc_weight * relativistic GAN term
                     through the frozen discriminator]; backward; clip; opt_g.step()
     discriminator:  loss_module(target=clips, recon=recon, disc_forward=True)  [both detached inside: relativistic loss + R1/R2
                     finite-difference penalty + centering]; backward; clip; opt_d.step()      (skipped when disc_weight == 0)
-    Under torch.distributed both gradient sets are reduced as sum(count * grad) / sum(count), as in `training_step`.
+    Under torch.distributed both gradient sets are reduced as sum(count * grad) / sum(count), as in `training_step` (overlap=True:
+    slice by slice behind the backward on a communication stream, dp.GradReducer).
     Returns the merged {'gen/..', 'disc/..'} dictionary of detached scalars and the token indices."""
+    red = _reducer_for(model, group, overlap)
+    g_towers = _towers(model) if red is not None else []
+    d_towers = _towers(loss_module) if red is not None else []
     opt_g.zero_grad(set_to_none=True)
-    recon, out = model(clips, token_counts)
-    loss, loss_dict = loss_module(target=clips, recon=recon)
-    loss.backward()
+    if red is not None:
+        red.attach(*g_towers)          # the discriminator's towers stay detached: frozen in this step, no gradients of their own
+        red.begin_step(len(clips))
+    try:
+        recon, out = model(clips, token_counts)
+        loss, loss_dict = loss_module(target=clips, recon=recon)
+        loss.backward()
+    finally:
+        if red is not None:
+            red.detach(*g_towers)
     g_params = [p for p in model.parameters() if p.grad is not None]
-    dp.allreduce_mean_by_count([p.grad for p in g_params], len(clips), group=group)
+    if red is not None:
+        red.finish()
+    else:
+        dp.allreduce_mean_by_count([p.grad for p in g_params], len(clips), group=group)
     if max_grad_norm:
         torch.nn.utils.clip_grad_norm_(g_params, max_grad_norm)
     opt_g.step()
     if opt_d is not None and getattr(loss_module, "disc_weight", 0.0) > 0.0:
         opt_d.zero_grad(set_to_none=True)
-        d_loss, d_dict = loss_module(target=clips, recon=recon, disc_forward=True)
-        loss_dict.update(d_dict)
-        d_loss.backward()
+        if red is not None:
+            red.attach(*d_towers)
+            red.begin_step(len(clips))
+        try:
+            d_loss, d_dict = loss_module(target=clips, recon=recon, disc_forward=True)
+            loss_dict.update(d_dict)
+            d_loss.backward()
+        finally:
+            if red is not None:
+                red.detach(*d_towers)
         d_params = [p for p in loss_module.disc_model.parameters() if p.grad is not None]
-        dp.allreduce_mean_by_count([p.grad for p in d_params], len(clips), group=group)
+        if red is not None:
+            red.finish()
+        else:
+            dp.allreduce_mean_by_count([p.grad for p in d_params], len(clips), group=group)
         if max_grad_norm:
             torch.nn.utils.clip_grad_norm_(d_params, max_grad_norm)
         opt_d.step()

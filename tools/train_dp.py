@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""BASELINE config #3: configs/tiny.yaml training on synthetic WebDataset-style shards, data-parallel over the GPUs of one node.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/train_dp.py --steps 20
+    python tools/train_dp.py --steps 20                       (single process)
+
+One process per GPU, backend "nccl" (= RCCL over xGMI).  Every rank writes nothing: rank 0 writes the seeded shards to a scratch
+directory first (or --shards points at existing ones), then every rank reads the shards it owns (shard i -> rank i % world), batches
+them under the reference's token budget (train_seq_len 6144, token_range [1, 128]: configs/tiny.yaml:57,65) and runs `--steps` steps
+of the reference's generator + discriminator step (train.py:64-107; L1 + relativistic GAN term, LPIPS off: no network) with the
+gradient all-reduce overlapped with the backward (titok_video_amd.dp.GradReducer) and the codebook-usage histogram all-reduced at the
+end.  The epoch ends collectively when the first rank runs out of batches.  Rank 0 prints ONE JSON line in bench.py's shape.
+--check: world-size-1 runs repeat the first step with overlap off and report the largest parameter difference (expected 0)."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shards", default="")
+    ap.add_argument("--n-shards", type=int, default=0, help="default 2 per rank")
+    ap.add_argument("--clips-per-shard", type=int, default=64)
+    ap.add_argument("--seq-len", type=int, default=6144)
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from titok_video_amd import dp
+    from titok_video_amd.codebook import CodebookLogger
+    from titok_video_amd.data import dynamic_batches, equal_steps
+    from titok_video_amd.model.losses import ReconstructionLoss
+    from titok_video_amd.model.titok import TiTok
+    from titok_video_amd.shards import shard_samples, write_synthetic_shards
+    from titok_video_amd.synthetic import seeded_titok_state, seeded_tower_state
+    from titok_video_amd.train import freeze_python_gc, gan_training_step, make_discriminator_optimizer, make_optimizer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = args.backend == "gloo"                    # CPU-side collective, every rank on cuda:0 (one-GPU boxes)
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    # ---- shards (rank 0 writes, everybody reads its own)
+    shard_dir = args.shards or os.path.join(tempfile.gettempdir(), "ttv_shards")
+    n_shards = args.n_shards or 2 * world
+    if not args.shards and rank == 0:
+        write_synthetic_shards(shard_dir, n_shards, args.clips_per_shard, seed=11)
+    if world > 1:
+        dist.barrier()
+    paths = sorted(os.path.join(shard_dir, f) for f in os.listdir(shard_dir) if f.endswith(".tar"))[:n_shards]
+
+    # ---- model, loss module (discriminator), optimisers: configs/tiny.yaml
+    levels = [7, 5, 5, 5, 5]
+    cfg = SimpleNamespace(
+        tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=levels, encoder_size="tiny", decoder_size="tiny"),
+                                  losses=SimpleNamespace(disc_weight=0.4, perceptual_weight=0.0, gram_weight=0.0, perceptual_samples_per_step=24,
+                                                         perceptual_sampling_size=128)),
+        discriminator=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], model_size="tiny"),
+                                      losses=SimpleNamespace(gp_weight=0.1, gp_noise=0.1, centering_weight=0.01)),
+        training=SimpleNamespace(main=SimpleNamespace(torch_compile=False, max_steps=1000)))
+    model = TiTok(cfg)
+    model.load_state_dict(seeded_titok_state(0), strict=True)
+    model = model.to(device, dtype).train()
+    loss_module = ReconstructionLoss(cfg)
+    loss_module.disc_model.load_state_dict(seeded_tower_state("encoder", "tiny", (4, 8, 8), 3, 1, seed=77), strict=True)
+    loss_module = loss_module.to(device, dtype).train()
+    opt_g = make_optimizer(model)
+    opt_d = make_discriminator_optimizer(loss_module) if loss_module is not None else None
+    logger = CodebookLogger(4375, world_size=world)
+
+    samples = shard_samples(paths, rank=rank, world_size=world, dtype=dtype, device=device, epochs=None)
+    raw_batches = dynamic_batches(samples, (4, 8, 8), (1, 128), args.seq_len, seed=100 + rank, drop_last=True)
+    freeze_python_gc()
+
+    def one_step(batch):
+        clips, counts = batch["video"], batch["token_counts"].tolist()
+        if loss_module is not None:
+            d, idx = gan_training_step(model, loss_module, clips, counts, opt_g, opt_d, overlap=not args.no_overlap)
+            loss = d.get("gen/total_loss", d.get("gen/loss", next(iter(d.values()))))
+        else:
+            from titok_video_amd.train import training_step
+            loss, _g, idx = training_step(model, clips, counts, opt_g, overlap=not args.no_overlap)
+        logger(torch.split(idx, counts))
+        return len(clips), loss
+
+    # the stand-in for the reference's loader workers (3 processes, video_dataset.py:211): batches are decoded / uploaded by a
+    # background thread a few steps ahead, so the timed region measures the training step, not tar extraction
+    import queue
+    import threading
+    q = queue.Queue(maxsize=4)
+
+    def producer():
+        up = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(up):
+            for smp in raw_batches:          # uploads + normalisation run on this thread's own stream
+                up.synchronize()
+                q.put(smp)
+        q.put(None)
+    threading.Thread(target=producer, daemon=True).start()
+
+    def fetched():
+        while True:
+            b = q.get()
+            if b is None:
+                return
+            yield b
+    it = iter(equal_steps(fetched()))
+    for _ in range(args.warmup):
+        one_step(next(it))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n_clips, loss = 0, None
+    for _ in range(args.steps):
+        n, loss = one_step(next(it))
+        n_clips += n
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(n_clips), elapsed], dtype=torch.float64, device="cpu" if (rehearsal or world == 1) else device)
+    if world > 1:
+        cl = tot[:1].clone()
+        dist.all_reduce(cl)
+        tm = tot[1:].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tot = torch.cat([cl, tm])
+    # codebook statistics: collective (every rank calls it the same number of times)
+    scores = logger.get_scores()
+    red = model.__dict__.get("_dp_reducer")
+    if rank == 0:
+        line = {"metric": "video clips/sec, training step (generator + discriminator), whole node", "value": float(tot[0] / tot[1]), "unit": "clips/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(tot[1]) / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic shards",
+                "config": {"workload": "BASELINE config #3: configs/tiny.yaml, synthetic tar shards, token budget %d, K ~ U[1,128], reference G + D step "
+                                       "(L1 + relativistic GAN, LPIPS off), AdamW, clip 1.0" % args.seq_len,
+                           "parallelism": f"dp{world}", "backend": args.backend if world > 1 else "none",
+                           "grad_allreduce": "after backward" if args.no_overlap else "overlapped with backward (per layer slice, communication stream)",
+                           "allreduce_bytes_last_backward": int(red.bytes_reduced) if red is not None else 0,
+                           "allreduce_slices_last_backward": int(red.slices) if red is not None else 0},
+                "loss_after_steps": float(loss), "codebook": scores}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
