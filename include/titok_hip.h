@@ -75,6 +75,17 @@ int ttv_vq_l2_argmin(const void* z, int dtype, int ldz, const void* codebook, in
 /* straight-through lookup: codes[r] = codebook[indices[r]] (the value the decoder sees; gradients pass to z unchanged). */
 int ttv_vq_lookup(const void* codebook, int dtype, int ldc, const int32_t* indices, int rows, int C, void* codes, int ldo, void* stream);
 
+/* ---- mixed bf16 / fp8 linears (BASELINE config #5; not a reference feature: the reference runs bf16 autocast) -------------
+ * Row-wise OCP e4m3 quantisation: y = gain ? RMSNorm(x) * gain (eps) : x;  scales[r] = max|y_r| / 448;  out[r] = e4m3(y_r / scales[r]).
+ * in [rows, width] (dtype, leading dim ld_in), out uint8 [rows, ld_out], width % 4 == 0, width <= 1024. */
+int ttv_quant_rows_fp8(const void* in, int dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
+                       int width, void* stream);
+/* y[M,N] (bf16) = (xq * x_scale[:,None]) @ (wq * w_scale[:,None])^T on v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation), K % 128 == 0.
+ * epilogue: 0 plain store; 1 to_qkv + rotary (rope_cs, d_model, gqa_dim as ttv_linear_qkv_rope; N = 2 d_model + 2 gqa_dim);
+ * 2 GEGLU (wq [2N, K], y[:, f] = gelu(acc[:, N+f]) * acc[:, f], as ttv_linear_geglu). */
+int ttv_linear_fp8(const void* xq, int ldx, const float* x_scale, const void* wq, int ldw, const float* w_scale, void* y, int ldy, int M, int N,
+                   int K, int epilogue, const float* rope_cs, int d_model, int gqa_dim, void* stream);
+
 /* ---- single ops (exported for parity tests; the tower entry points below chain them) ------------------ */
 
 /* RMSNorm (flash_attn RMSNorm as used at blocks.py:51-52,66 / transformer.py:42,77,122-123):
@@ -214,6 +225,11 @@ typedef struct ttv_layer_weights {
   /* optional (bf16, any width; used where to_qkv_pn is not): an inference copy of to_qkv whose q rows carry the same factor;
    * NULL = use to_qkv and the plain attention kernel */
   const void* to_qkv_qs;
+  /* optional mixed bf16 / fp8 linears (BASELINE config #5; bf16 towers, width % 128 == 0, used where the folded width-256 kernels are
+   * not): to_qkv (its q rows pre-scaled like to_qkv_qs when that is given) and w12 in OCP e4m3 with one fp32 scale per weight row
+   * (ttv_quant_rows_fp8).  When non-NULL the pre-norm output is quantised per token and the two projections run on the fp8 MFMA. */
+  const void* to_qkv_f8; const float* to_qkv_f8_scale;
+  const void* w12_f8; const float* w12_f8_scale;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {

@@ -90,7 +90,18 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
     // ---- attention sub-layer (transformer.py:85-104) ----
-    if (!qkv_ready) {
+    // mixed bf16 / fp8 (config #5): the pre-norm output is quantised to e4m3 per token (into the xn buffer: L x dm bytes of values,
+    // then L fp32 scales) and the projection runs on the fp8 MFMA; everything downstream is unchanged
+    const bool f8_qkv = dt == TTV_BF16 && lw.to_qkv_f8 && lw.to_qkv_f8_scale && dm % 128 == 0 && !(dm == 256 && lw.to_qkv_pn);
+    const bool f8_w12 = dt == TTV_BF16 && lw.w12_f8 && lw.w12_f8_scale && dm % 128 == 0 && !(dm == 256 && lw.w12_pn);
+    float* const f8_scales = reinterpret_cast<float*>(ws.xn + (((size_t)L * dm + 255) & ~(size_t)255));
+    if (!qkv_ready && f8_qkv) {
+      TTV_TRY(ttvk_quant_rows_fp8(ws.x, dt, dm, lw.pre_ln, d->eps, ws.xn, dm, f8_scales, L, dm, s));
+      GemmArgs a = {};
+      a.dtype = dt; a.x = ws.xn; a.ldx = dm; a.w = lw.to_qkv_f8; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+      a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+      TTV_TRY(ttvk_gemm_fp8(EPI_QKV_ROPE, a, f8_scales, lw.to_qkv_f8_scale, s));
+    } else if (!qkv_ready) {
       const bool fold_qkv = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn;
       if (!fold_qkv) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
       GemmArgs a = {};
@@ -141,12 +152,19 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
     const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
+    if (f8_w12) {
+      TTV_TRY(ttvk_quant_rows_fp8(ws.x, dt, dm, lw.ffd_norm, d->eps, ws.xn, dm, f8_scales, L, dm, s));
+      GemmArgs f = {};
+      f.dtype = dt; f.x = ws.xn; f.ldx = dm; f.w = lw.w12_f8; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
+      TTV_TRY(ttvk_gemm_fp8(EPI_GEGLU, f, f8_scales, lw.w12_f8_scale, s));
+    } else {
     if (!fold_ffd) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
     f.dtype = dt;
     f.prenorm = fold_ffd; f.eps = d->eps;
     f.x = fold_ffd ? ws.x : ws.xn; f.ldx = dm; f.w = fold_ffd ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
     TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
+    }
     GemmArgs f3 = {};
     f3.dtype = dt;
     f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = L; f3.N = dm; f3.K = d->inner; f3.resid = ws.x; f3.ldr = dm;
@@ -199,6 +217,25 @@ int ttv_vq_l2_argmin(const void* z, int dtype, int ldz, const void* codebook, in
 int ttv_vq_lookup(const void* codebook, int dtype, int ldc, const int32_t* indices, int rows, int C, void* codes, int ldo, void* stream) {
   TTV_CHECK_ARG(rows == 0 || (codebook && indices && codes), "vq_lookup: null buffer");
   return ttvk_vq_lookup(codebook, dtype, ldc, indices, rows, C, codes, ldo, (hipStream_t)stream);
+}
+
+int ttv_quant_rows_fp8(const void* in, int dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
+                       int width, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (in && out && scales), "quant_rows_fp8: null buffer");
+  return ttvk_quant_rows_fp8(in, dtype, ld_in, gain, eps, out, ld_out, scales, rows, width, (hipStream_t)stream);
+}
+
+int ttv_linear_fp8(const void* xq, int ldx, const float* x_scale, const void* wq, int ldw, const float* w_scale, void* y, int ldy, int M, int N,
+                   int K, int epilogue, const float* rope_cs, int d_model, int gqa_dim, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (xq && wq && y), "linear_fp8: null buffer");
+  TTV_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "linear_fp8: epilogue 0 (store), 1 (qkv + rotary) or 2 (GEGLU)");
+  GemmArgs a = {};
+  a.dtype = TTV_BF16; a.x = xq; a.ldx = ldx; a.w = wq; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy;
+  if (epilogue == 1) {
+    TTV_CHECK_ARG(rope_cs && N == 2 * d_model + 2 * gqa_dim, "linear_fp8: qkv epilogue needs rope_cs and N = 2 d_model + 2 gqa_dim");
+    a.rope_cs = rope_cs; a.rope_q_end = d_model; a.rope_k_begin = 2 * d_model; a.rope_k_end = 2 * d_model + gqa_dim;
+  }
+  return ttvk_gemm_fp8(epilogue == 0 ? EPI_STORE : epilogue == 1 ? EPI_QKV_ROPE : EPI_GEGLU, a, x_scale, w_scale, (hipStream_t)stream);
 }
 
 int ttv_rmsnorm(const void* in, int in_dtype, int ld_in, const int32_t* src_rows, void* out, int out_dtype, int ld_out,

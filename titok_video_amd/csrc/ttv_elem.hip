@@ -69,6 +69,78 @@ int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, v
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-wise fp8 (OCP e4m3) quantisation for the mixed bf16 / fp8 linears (BASELINE config #5; not a reference feature - the
+// reference runs bf16 autocast, configs/tiny.yaml:70): optionally the RMSNorm in front of the linear (transformer.py:48,86) in
+// the same pass.  y = gain ? x * rsqrt(mean(x^2) + eps) * gain : x;  scale[r] = max|y| / 448;  q = round_e4m3(y / scale[r]).
+// One wave per row, 4 elements per lane and step; v_cvt_pk_fp8_f32 packs two values per call.
+// ------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void k_quant_rows_fp8(const TI* __restrict__ in, int ld_in, const float* __restrict__ gain, float eps,
+                                                        uint8_t* __restrict__ out, int ld_out, float* __restrict__ scales, int rows, int d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  const TI* p = in + (size_t)r * ld_in;
+  f32x4 v[MAX_ITERS];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < d) {
+      v[it] = Vec4<TI>::load(p + c);
+      ss += v[it][0] * v[it][0] + v[it][1] * v[it][1] + v[it][2] * v[it][2] + v[it][3] * v[it][3];
+    }
+  }
+  float amax = 0.f;
+  if (gain) {
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+#pragma unroll
+    for (int it = 0; it < MAX_ITERS; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < d) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = round_to<TI>(v[it][e] * rstd * g[e]);     // what the bf16 path would hand the linear
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[it][e]));
+  amax = wave_max(amax);
+  const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / scale;
+  if (lane == 0) scales[r] = scale;
+  uint8_t* q = out + (size_t)r * ld_out;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < d) {
+      int w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[it][0] * inv, v[it][1] * inv, w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[it][2] * inv, v[it][3] * inv, w, true);
+      *reinterpret_cast<int*>(q + c) = w;
+    }
+  }
+}
+
+int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
+                        int d, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS, "quant_rows_fp8: width %d must be a multiple of 4 and <= 1024", d);
+  TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && (uintptr_t)out % 4 == 0, "quant_rows_fp8: leading dims must be multiples of 4");
+  dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
+  if (in_dtype == TTV_BF16) hipLaunchKernelGGL((k_quant_rows_fp8<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, ld_in, gain, eps, (uint8_t*)out, ld_out, scales, rows, d);
+  else if (in_dtype == TTV_F32) hipLaunchKernelGGL((k_quant_rows_fp8<float>), grid, dim3(256), 0, s, (const float*)in, ld_in, gain, eps, (uint8_t*)out, ld_out, scales, rows, d);
+  else { ttv_set_error("quant_rows_fp8: bad dtype"); return TTV_ERR_INVALID; }
+  TTV_CHECK_LAUNCH("quant_rows_fp8");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rows that hold RMSNorm(mask_token * ones(d)) * gain: encoder latent rows (blocks.py:96), decoder patch rows
 // (blocks.py:167).  Every such row is the same vector; mean(m^2) over a constant row is m^2.
 // ------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ struct GemmDev {
   ClipPtrs clips;
   const int* clip_desc; const int* patch_rows; const int* row_seq;
   const int* x_rows;   // k256: GEMM row t reads x row x_rows[t] (NULL = identity)
+  const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma)
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
 };
 
@@ -484,6 +485,149 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16_dma(GemmDev p, int n_ftile
   int tok[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
+  if (DUAL) {
+    int feat[2];
+    f32x4 ax[2][NJ], ag[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
+    }
+    epilogue_tile<EPI, bf16_t, 2, NJ>(p, tok, feat, ax, ag, kq);
+  } else {
+    int feat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
+    epilogue_tile<EPI, bf16_t, 4, NJ>(p, tok, feat, acc, acc, kq);
+  }
+}
+
+// ================================================================================================
+// Mixed bf16 / fp8 linears (BASELINE config #5): both operands in OCP e4m3 with one fp32 scale per row (token / weight row;
+// k_quant_rows_fp8), products on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales - twice the bf16 MFMA rate and half the
+// operand bytes through L2 and LDS - fp32 accumulation, the two row scales applied to the accumulator before the usual epilogue
+// (output bf16).  A 128-element k-tile of fp8 is 128 bytes per row: the LDS image, its XOR swizzle and the LDS-DMA staging are
+// byte for byte those of k_gemm_bf16_dma.  K order inside a k-tile: lane group kq supplies 16-byte chunks kq and kq + 4 of its
+// row as its 32 operand bytes - any assignment works as long as both operands use the same one (the instruction pairs element j
+// of lane group kq of A with element j of lane group kq of B).
+// ================================================================================================
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+
+template <int EPI, int NJ>
+__global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles) {
+  constexpr bool DUAL = (EPI == EPI_GEGLU);
+  constexpr int FT = DUAL ? 64 : TF;
+  constexpr int TTK = 32 * NJ;
+  constexpr int XI = TTK / 32;
+  constexpr int BK8 = 128;                      // fp8 elements = bytes per k-tile and row
+  __shared__ __attribute__((aligned(16))) uint4 lds[2][(TF + TTK) * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wave & 1, wt = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int fbase = (tile % n_ftiles) * FT;
+  const int tbase = (tile / n_ftiles) * TTK;
+  const uint8_t* W = (const uint8_t*)p.w;
+  const uint8_t* X = (const uint8_t*)p.x;
+
+  const int lr = lane >> 3, lp = lane & 7;
+  uint32_t woff[4], xoff[XI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lr;
+    int wr;
+    if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
+    else wr = fbase + row;
+    wr = wr < p.w_rows ? wr : p.w_rows - 1;
+    woff[i] = (uint32_t)wr * (uint32_t)p.ldw + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = wave * (8 * XI) + i * 8 + lr;
+    int xr = tbase + row;
+    xr = xr < p.M ? xr : p.M - 1;
+    xoff[i] = (uint32_t)xr * (uint32_t)p.ldx + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&lds[0][0];
+  constexpr uint32_t BUFB = (TF + TTK) * 128;
+#define G8_DMA(voff_, base_, dst_)                                                                               \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                 \
+  } while (0)
+#define G8_STAGE(kt_, buf_)                                                                                      \
+  do {                                                                                                           \
+    const uint8_t* wb__ = W + (size_t)(kt_) * BK8;                                                               \
+    const uint8_t* xb__ = X + (size_t)(kt_) * BK8;                                                               \
+    const uint32_t dw__ = lds0 + (buf_) * BUFB + wave * 4096;                                                    \
+    const uint32_t dx__ = lds0 + (buf_) * BUFB + TF * 128 + wave * (1024 * XI);                                  \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) G8_DMA(woff[i__], wb__, dw__ + i__ * 1024);              \
+    _Pragma("unroll") for (int i__ = 0; i__ < XI; ++i__) G8_DMA(xoff[i__], xb__, dx__ + i__ * 1024);             \
+  } while (0)
+
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nk = p.K / BK8;
+  G8_STAGE(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) G8_STAGE(kt + 1, buf ^ 1);
+    v8i32 a[4], b[NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+      const int sw = (arow >> 1) & 7;
+      const uint4 lo = lds[buf][arow * 8 + (kq ^ sw)], hi = lds[buf][arow * 8 + ((kq + 4) ^ sw)];
+      a[i] = (v8i32){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int brow = wt * (16 * NJ) + j * 16 + l15;
+      const int sw = (brow >> 1) & 7;
+      const uint4 lo = lds[buf][TF * 8 + brow * 8 + (kq ^ sw)], hi = lds[buf][TF * 8 + brow * 8 + ((kq + 4) ^ sw)];
+      b[j] = (v8i32){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0 /* A: fp8 e4m3 */, 0 /* B: fp8 e4m3 */,
+                                                                      0, 0x7F7F7F7F /* E8M0 1.0 */, 0, 0x7F7F7F7F);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+#undef G8_STAGE
+#undef G8_DMA
+
+  // dequantise: acc *= x_scale[token] * w_scale[feature]
+  int tok[NJ];
+  float sx[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
+    sx[j] = p.x_scale[tok[j] < p.M ? tok[j] : p.M - 1];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int f;
+    if (DUAL) f = (i < 2 ? fbase + wf * 32 + i * 16 : p.N + fbase + wf * 32 + (i - 2) * 16) + kq * 4;
+    else f = fbase + wf * 64 + i * 16 + kq * 4;
+    f = f + 3 < p.w_rows ? f : p.w_rows - 4;
+    const f32x4 sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + f);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] *= sx[j] * sw4[e];
+  }
   if (DUAL) {
     int feat[2];
     f32x4 ax[2][NJ], ag[2][NJ];
@@ -1141,6 +1285,39 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
   return TTV_OK;
 }
 
+// y[M,N] (bf16) = dequant(xq[M,K] e4m3, x_scale[M]) @ dequant(wq[N(or 2I),K] e4m3, w_scale)^T with the EPI_STORE / EPI_QKV_ROPE / EPI_GEGLU epilogues
+int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, const float* w_scale, hipStream_t s) {
+  if (a.M == 0 || a.N == 0) return TTV_OK;
+  TTV_CHECK_ARG(epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU, "gemm_fp8: epilogue must be STORE, QKV_ROPE or GEGLU");
+  TTV_CHECK_ARG(a.K > 0 && a.K % 128 == 0 && a.N % 8 == 0, "gemm_fp8: K %% 128, N %% 8");
+  TTV_CHECK_ARG(a.ldx % 16 == 0 && a.ldw % 16 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0),
+                "gemm_fp8: 16-byte row alignment");
+  TTV_CHECK_ARG(x_scale && w_scale && (uintptr_t)w_scale % 16 == 0, "gemm_fp8: scales missing / unaligned");
+  TTV_CHECK_ARG((uint64_t)a.M * (uint64_t)a.ldx < (1ull << 32), "gemm_fp8: operand too large for 32-bit offsets");
+  GemmDev d = {};
+  d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs;
+  d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = a.ldy; d.ldr = a.ldr; d.M = a.M; d.N = a.N; d.K = a.K; d.alpha = a.alpha;
+  d.w_rows = (epi == EPI_GEGLU) ? 2 * a.N : a.N;
+  d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end; d.eps = a.eps; d.debug = g_ttv_debug;
+  d.x_scale = x_scale; d.w_scale = w_scale;
+  if (epi == EPI_QKV_ROPE) TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 128 == 0 && a.rope_k_begin % 128 == 0 && a.rope_k_end % 128 == 0, "gemm_fp8: rotary ranges must be multiples of 128 columns");
+  const int ft = (epi == EPI_GEGLU) ? 64 : TF;
+  const int nf = ttv_cdiv(d.N, ft), nt = ttv_cdiv(d.M, TT), nt160 = ttv_cdiv(d.M, 160);
+  const long cost128 = (long)ttv_cdiv(nf * nt, 512) * 128, cost160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
+  const bool t160 = cost160 < cost128;
+  const int kc = epi == EPI_STORE ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : TTV_KC_GEMM_GEGLU;
+  TtvProfScope prof(kc, s);
+#define F8_LAUNCH(E_)                                                                                              \
+  do {                                                                                                              \
+    if (t160) hipLaunchKernelGGL((k_gemm_fp8_dma<E_, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);                \
+    else hipLaunchKernelGGL((k_gemm_fp8_dma<E_, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);                        \
+  } while (0)
+  if (epi == EPI_STORE) F8_LAUNCH(EPI_STORE); else if (epi == EPI_QKV_ROPE) F8_LAUNCH(EPI_QKV_ROPE); else F8_LAUNCH(EPI_GEGLU);
+#undef F8_LAUNCH
+  TTV_CHECK_LAUNCH("gemm_fp8");
+  return TTV_OK;
+}
+
 bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K) { return dtype == TTV_BF16 && N == 256 && K % 8 == 0; }
 
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
@@ -1163,6 +1340,7 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.norm_gain = a.norm_gain;
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;
   d.x_rows = a.x_rows;
+  d.x_scale = nullptr; d.w_scale = nullptr;
   TTV_CHECK_ARG(!a.x_rows || (a.dtype == TTV_BF16 && a.K == 256 && a.N % 8 == 0 && epi != EPI_RESID_NORM), "gemm: x_rows needs the bf16 K=256 kernel");
   if (epi == EPI_STORE_PATCH || a.gather) {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };

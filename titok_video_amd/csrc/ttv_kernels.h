@@ -22,6 +22,8 @@ int ttvk_patch_copy(bool scatter, void* const* clips, const int* clip_desc, int 
                     int C, void* patches, int ld, int dtype, int max_patches, hipStream_t s);
 int ttvk_rope_apply(void* x, int dtype, int ld, int rows, int heads, const float* cs, hipStream_t s);
 int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t s);
+int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
+                        int d, hipStream_t s);
 
 // ---- ttv_gemm.hip ----
 // out^T-oriented GEMM: the MFMA "row" side is the output feature (W rows), the "column" side the token (X rows),
@@ -65,6 +67,7 @@ struct GemmArgs {
 };
 struct ClipPtrs { void* p[TTV_MAX_CLIPS_PER_LAUNCH]; };
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, const float* w_scale, hipStream_t s);
 bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 
 // ---- ttv_attn.hip ----

@@ -129,7 +129,7 @@ class _Tower(nn.Module):
 
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
         params = self._param_list()
-        key = (dtype, str(device), _versions(params))
+        key = (dtype, str(device), _versions(params), bool(getattr(self, "fp8_linears", False)))
         if _PACK_CHECK:
             key = key + (float(sum(p.detach().double().sum() for p in params)),)
         if self._pack is None or self._pack_key != key:
@@ -332,6 +332,24 @@ class _WeightPack:
             keep.append(t)
             return t.data_ptr()
 
+        use_f8 = bool(getattr(tower, "fp8_linears", False)) and dtype == torch.bfloat16 and not fold and tower.width % 128 == 0
+
+        def f8_rows(w, q_rows=0):
+            """(pointer to e4m3 [N, K], pointer to fp32 row scales) of a linear weight for the mixed bf16 / fp8 path; the q rows carry
+            the softmax exponent factor like to_qkv_qs when that is in use."""
+            if not use_f8:
+                return None, None
+            t = w.detach().to(device=device, dtype=torch.float32).clone()
+            if q_rows and q_scale is not None:
+                t[:q_rows] *= q_scale
+            t = t.contiguous()
+            q = torch.empty(t.shape, dtype=torch.uint8, device=device)
+            sc = torch.empty(t.shape[0], dtype=torch.float32, device=device)
+            _lib.check(_lib.lib().ttv_quant_rows_fp8(t.data_ptr(), _lib.TTV_F32, t.shape[1], None, 0.0, q.data_ptr(), t.shape[1], sc.data_ptr(),
+                                                     t.shape[0], t.shape[1], _lib.stream_ptr(device)), "ttv_quant_rows_fp8")
+            keep.extend([t, q, sc])
+            return q.data_ptr(), sc.data_ptr()
+
         def folded_tensor(w, g, q_rows=0):
             t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :])
             if q_rows and q_scale is not None:
@@ -382,7 +400,10 @@ class _WeightPack:
             a, f = ml.attn_layer[i], ml.ffd_layer[i]
             pack_ptr, pack_rows = mlp_packed(f.w12.weight, f.norm.weight, f.w3.weight, a.out_proj.weight,
                                              ml.attn_layer[i + 1] if i + 1 < n else None)
+            qkv8, qkv8s = f8_rows(a.to_qkv.weight, q_rows=tower.width)
+            w128, w128s = f8_rows(f.w12.weight)
             self.layers[i] = _lib.LayerWeights(
+                to_qkv_f8=qkv8, to_qkv_f8_scale=qkv8s, w12_f8=w128, w12_f8_scale=w128s,
                 pre_ln=gain(a.pre_ln.weight), to_qkv=lin(a.to_qkv.weight), out_proj=lin(a.out_proj.weight),
                 ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
