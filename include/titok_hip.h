@@ -173,6 +173,9 @@ int ttv_decoder_embed(const void* codes, int token_size, const void* w, const vo
 #define TTV_ATTN_GATE 1
 #define TTV_ATTN_PAIRED 2
 #define TTV_ATTN_QSCALED 4   /* bf16: the q columns already carry the factor head_dim^-0.5 * log2(e) (see ttv_layer_weights.qkv_q_prescaled) */
+#define TTV_ATTN_ALLFULL 8   /* the table holds full items only (mode 0 everywhere, padding entries allowed) */
+#define TTV_ATTN_PIPE 16     /* bf16, with TTV_ATTN_QSCALED | TTV_ATTN_ALLFULL and no tape: run the software-pipelined kernel (opt-in: measured
+                                slower than the plain loop, see ttv_attn.hip; the towers set it under the environment switch TTV_ATTN_PIPE=1) */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 
@@ -268,6 +271,7 @@ typedef struct ttv_batch {
   int32_t n_blocks64;
   int32_t qblocks_paired;      /* 1: entries 2j, 2j+1 of every XCD list of `qblocks` are the same query rows of two q-heads sharing
                                   a kv-head (ttv_attention flag TTV_ATTN_PAIRED); 0: no such guarantee */
+  int32_t qblocks_all_full;    /* 1: `qblocks` holds full items only (ttv_attention flag TTV_ATTN_ALLFULL) */
 } ttv_batch;
 
 /* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =

@@ -2,7 +2,7 @@
 // (replaces flash_attn_varlen_func at reference model/base/transformer.py:100 and the gate at :103).
 //
 // bf16 kernel (head_dim 64).  One workgroup = 4 waves = 128 query rows of one (sequence, q-head); each wave owns
-// 32 queries.  K/V tiles of 64 keys are staged by LDS-DMA into double-buffered, XOR-swizzled LDS (124 VGPRs: 4 blocks per CU).
+// 32 queries.  K/V tiles of 64 keys are staged by LDS-DMA into double-buffered, XOR-swizzled LDS (164 VGPRs with pre-scaled q and the gate: 3 blocks per CU).
 // "Half items" (work-table mode 1): 64 query rows, wave pairs split the key range and merge their (O, m, l) at the end.
 //   S^T = K Q^T   : mfma_f32_32x32x16_bf16 with the KEY on the MFMA row and the QUERY on the lane (col = lane&31),
 //                   so a lane holds 32 scores of ONE query: row max / row sum are in-lane plus one xor-32 exchange.
@@ -414,12 +414,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
 
   }
 #ifdef ATTN_STAMPS
-  if (stamps && blockIdx.x % 37 == 0 && lane == 0) {
-    long long* dst = stamps + ((size_t)(blockIdx.x / 37) * 4 + wave) * 8;
-    for (int i = 0; i < 6; ++i) dst[i] = (long long)st_acc__[i];
-    dst[6] = nkt;
-    dst[7] = (long long)st_prev__;
-  }
+  const unsigned long long st_loop_end__ = st_prev__;
 #endif
   if (MSUM) l_run = o_sum[0];      // row 0 of the third tile (lanes 0..31); lanes 32..63 hold its row 4 = 0
   } else {
@@ -578,6 +573,430 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
         if (store) *reinterpret_cast<uint4*>(orow + dt * 32 + 16 * gp + 8 * h) = o16;
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined bf16 kernel for tables of FULL items with pre-scaled q.  OPT-IN (flag TTV_ATTN_PIPE; towers: TTV_ATTN_PIPE=1): correct (same tests as
+// k_attn_bf16) but 6-10 % SLOWER than it on MI355X at the benchmark shape (62.8 vs 59.3 us per launch inside bench.py, 67 vs 60 us
+// back to back); kept as the measured record of what in-wave pipelining buys on this part - nothing - and why.
+//
+// Idea.  k_attn_bf16 walks S MFMAs -> row maximum -> exp2 / pack -> PV MFMAs strictly in sequence in every wave.  Here
+//   * the phases of neighbouring steps overlap INSIDE the wave.  A step u is a 32-key half of a 64-key tile (two score sets of
+//     16 registers; with 64-key steps the loop wants 184 VGPRs and spills at the 168 of three waves per SIMD):
+//         step u :  PV(u-1) | first half of softmax(S(u)),  then  S(u+1) = K(u+1) Q^T | second half      (4 + 4 MFMAs)
+//     and the LDS fragments of a block are read one block ahead of their MFMAs;
+//   * there is NO row maximum on the main path.  The reference m of a row is the maximum of its first 32 scores; later steps
+//     compute p = exp2(s - m) against it unchecked and look at the lane's row sum afterwards: only when that exceeds
+//     2^ATTN_PIPE_THR (this includes inf / nan) a rare branch takes the step's raw scores again (4 MFMAs, K straight from global
+//     memory), moves the reference to their true maximum, rescales O and l, and recomputes the step's p.  Any reference gives
+//     the same quotient; bf16 P and fp32 sums have the range for 2^40;
+//   * LDS addresses are six loop-invariant registers plus the ring slot's scalar offset plus an immediate, row sums and the
+//     reference subtraction use the packed fp32 add, the DMA sources are running 64-bit bases (one asm statement per tile).
+// Tile t of K is read in steps 2t-1 and 2t, tile t of V in steps 2t+1 and 2t+2: ONE barrier per tile, at the top of the odd step
+// 2t+1, where K(t+1) and V(t) must have landed and the slots of K(t) and V(t-1) fall free.  Three-slot rings, filled two tile
+// periods ahead by LDS-DMA (K(t+3), V(t+2) issued there; tile indices past the end re-fetch the last tile so that every tile issues
+// the same four DMA instructions per wave and the counted wait `s_waitcnt vmcnt(4)` is a constant); raw s_barrier, because a
+// __syncthreads() would drain the DMA in flight.  48 KB LDS, 141 VGPRs, three blocks per CU.
+//
+// Why it does not pay ("attention: where the time goes"; tools/ubench/valu_rates.hip, tools/attn_knockout.sh):
+//   * on one SIMD, matrix and vector work barely overlap, neither across waves nor inside one: 16 MFMAs + 96 plain + 32 exp2
+//     instructions per iteration cost 584 cycles per wave at three waves per SIMD whether interleaved or in two phases - the sum of
+//     the MFMA-only (350) and the vector-only loop (291) is 641.  A wave's phases being serial is therefore not the loss;
+//   * knocking ingredients out of this kernel (garbage results, same launch): no in-loop DMA -4 us, no barrier -2 us, no LDS
+//     fragment reads -6.5 us, a quarter of the softmax arithmetic -11 us, all four 65 -> 43 us: the costs ADD, nothing hides
+//     behind anything else, and ~10 us of every launch are the two rounds' prologues and epilogues.
+// ------------------------------------------------------------------------------------------------
+#define ATTN_PIPE_THR 40.0f
+// knock-out switches of diagnostic builds (tools/attn_knockout.sh): what does the launch cost WITHOUT the in-loop DMA, the
+// barrier, three quarters of the exp2 arithmetic?  Results are garbage then; the product build has all three at 0.
+#ifndef PP_KO_DMA
+#define PP_KO_DMA 0
+#endif
+#ifndef PP_KO_BARRIER
+#define PP_KO_BARRIER 0
+#endif
+#ifndef PP_KO_LDS
+#define PP_KO_LDS 0
+#endif
+#ifndef PP_KO_VALU
+#define PP_KO_VALU 0
+#endif
+template <bool GATE>
+__global__ __launch_bounds__(256, 3) void k_attn_pipe(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
+                                                      const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
+                                                      int rep, float defer_thr, long long* stamps) {
+  __shared__ __attribute__((aligned(16))) uint4 kl[3][KB * 8];
+  __shared__ __attribute__((aligned(16))) uint4 vl[3][KB * 8];
+#ifdef ATTN_STAMPS
+  unsigned long long st_entry__;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry__)::"memory");
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int tix = blockIdx.x;
+  const int seq = qblocks[4 * tix], q0 = qblocks[4 * tix + 1], head = qblocks[4 * tix + 2];
+  if (seq < 0) return;
+  const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int kvh = head / rep;
+  const bf16_t* qbase = qkvg + (size_t)s0 * ld + head * 64;
+  const bf16_t* gbase = qkvg + (size_t)s0 * ld + d_model + head * 64;
+  const bf16_t* kbase = qkvg + (size_t)s0 * ld + 2 * d_model + kvh * 64;
+  const bf16_t* vbase = kbase + gqa;
+  const int qrow = q0 + wave * 32 + r;
+  const int qrc = qrow < S ? qrow : S - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8);
+  // a use of q ahead of the DMA: the compiler's wait for these loads (it cannot count the DMA of the asm statements, so it waits for
+  // vmcnt(0)) lands here and not in front of the first MFMA, where it would drain the whole prologue
+  asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+
+  // DMA shares: wave w stages tile rows 8 w + (lane >> 3) and that + 32 of K and of V.  Rows 32 apart have the same chunk swizzle
+  // (K: (row >> 1) & 7, V: ((row >> 1) & 1) << 2), so ONE per-lane offset serves both instructions of an operand (the 32 rows go
+  // into the scalar base) - two VGPRs live through the loop instead of four.
+  const uint32_t kl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&kl[0][0];
+  const uint32_t vl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&vl[0][0];
+  const int drow = wave * 8 + (lane >> 3);
+  const int kc = ((lane & 7) ^ ((drow >> 1) & 7)) * 8;
+  const int vc = ((lane & 7) ^ (((drow >> 1) & 1) << 2)) * 8;
+  const uint32_t dK = (uint32_t)(drow * ld + kc) * 2u;
+  const uint32_t dV = (uint32_t)(drow * ld + vc) * 2u;
+  const int nkt = (S + KB - 1) / KB;
+#define PP_DMA(voff_, base_, dst_)                                                                               \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                 \
+  } while (0)
+  // one operand tile (two DMA instructions per wave, always): tile index clamped to the last one, rows past the end clamped
+#define PP_TILE(base_, lds_, kt_, soff_, c_, d_)                                                                 \
+  do {                                                                                                           \
+    const int ktc__ = (kt_) < nkt ? (kt_) : nkt - 1;                                                             \
+    const int key0__ = ktc__ * KB;                                                                               \
+    const bf16_t* b__ = (base_) + (size_t)key0__ * ld;                                                           \
+    const uint32_t dst__ = (lds_) + (soff_) + wave * 1024;                                                       \
+    if (key0__ + KB <= S) {                                                                                      \
+      PP_DMA(d_, b__, dst__);                                                                                    \
+      PP_DMA(d_, b__ + (size_t)32 * ld, dst__ + 4096);                                                           \
+    } else {                                                                                                     \
+      const int lim__ = S - 1 - key0__;                                                                          \
+      const int g0__ = drow < lim__ ? drow : lim__, g1__ = drow + 32 < lim__ ? drow + 32 : lim__;                \
+      PP_DMA((uint32_t)(g0__ * ld + (c_)) * 2u, b__, dst__);                                                     \
+      PP_DMA((uint32_t)(g1__ * ld + (c_)) * 2u, b__, dst__ + 4096);                                              \
+    }                                                                                                            \
+  } while (0)
+
+  // the four DMA instructions of a tile in ONE statement (M0 saved and restored once), sources = running 64-bit bases: tiles
+  // before the sequence's last one need no clamping
+#define PP_DMA4(kp_, kp32_, kdst_, vp_, vp32_, vdst_)                                                            \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\t"                                                                          \
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"                             \
+                 "s_add_u32 m0, %5, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"                     \
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"                             \
+                 "s_add_u32 m0, %8, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"                     \
+                 "s_mov_b32 m0, %0"                                                                              \
+                 : "=&s"(keep__)                                                                                 \
+                 : "v"(dK), "v"(dV), "s"(kp_), "s"(kp32_), "s"(kdst_), "s"(vp_), "s"(vp32_), "s"(vdst_)           \
+                 : "memory", "scc");                                                                             \
+  } while (0)
+
+  // lane-constant LDS addresses (see k_attn_bf16); the ring slot is a scalar byte offset, the half an immediate
+  const int ksw = (r >> 1) & 7;
+  const char* const kbase_lds = reinterpret_cast<const char*>(&kl[0][0]);
+  const char* const vbase_lds = reinterpret_cast<const char*>(&vl[0][0]);
+  const char* const ka0 = kbase_lds + r * 128 + (((0 * 2 + h) ^ ksw) << 4);
+  const char* const ka1 = kbase_lds + r * 128 + (((1 * 2 + h) ^ ksw) << 4);
+  const char* const ka2 = kbase_lds + r * 128 + (((2 * 2 + h) ^ ksw) << 4);
+  const char* const ka3 = kbase_lds + r * 128 + (((3 * 2 + h) ^ ksw) << 4);
+  const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, g16 = (lane >> 4) & 1;
+  const int vsw = (tq >> 1) & 1;
+  const int vlane = (4 * h + tq) * 128 + (g16 * 2 + (tp >> 1)) * 16 + (tp & 1) * 8;
+  const char* const va0 = vbase_lds + vlane + (vsw ? 64 : 0);
+  const char* const va1 = vbase_lds + vlane + (vsw ? 0 : 64);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+  f32x16 o_acc[2] = {zero16, zero16};
+  float m_run = 0.f, l_run = 0.f;
+  const float p_limit = __builtin_amdgcn_exp2f(defer_thr);
+  bf16x8 pf0, pf1;                    // P(u-1) as B fragments (keys 0-15 and 16-31 of the half)
+  f32x16 sA, sB;                      // the two score sets (raw scores)
+  bf16x8 kf0, kf1, kf2, kf3;          // K fragments of the next S block, V fragments of the next PV block: read from LDS one
+  bf16x8 vf00, vf10, vf01, vf11;      // block ahead of their MFMAs, so that no block opens on an exposed LDS round trip
+
+  // fragment reads of half J_ of the ring slot at byte offset soff_ (J_: literal)
+#define PP_LOADK(soff_, J_)                                                                                      \
+  do {                                                                                                           \
+    if (PP_KO_LDS) { kf0 = qf[0]; kf1 = qf[1]; kf2 = qf[2]; kf3 = qf[3]; break; }                                \
+    kf0 = *reinterpret_cast<const bf16x8*>(ka0 + (soff_) + (J_) * 4096);                                         \
+    kf1 = *reinterpret_cast<const bf16x8*>(ka1 + (soff_) + (J_) * 4096);                                         \
+    kf2 = *reinterpret_cast<const bf16x8*>(ka2 + (soff_) + (J_) * 4096);                                         \
+    kf3 = *reinterpret_cast<const bf16x8*>(ka3 + (soff_) + (J_) * 4096);                                         \
+  } while (0)
+#define PP_VFRAG(va_, OFF_)                                                                                      \
+  ({                                                                                                             \
+    const bf16x4 lo__ = lds_read_tr16((va_) + (OFF_)), hi__ = lds_read_tr16((va_) + (OFF_) + 1024);              \
+    (bf16x8){lo__[0], lo__[1], lo__[2], lo__[3], hi__[0], hi__[1], hi__[2], hi__[3]};                            \
+  })
+#define PP_LOADV(soff_, J_)                                                                                      \
+  do {                                                                                                           \
+    if (PP_KO_LDS) { vf00 = vf10 = vf01 = vf11 = qf[0]; break; }                                                 \
+    const char* v0__ = va0 + (soff_);                                                                            \
+    const char* v1__ = va1 + (soff_);                                                                            \
+    vf00 = PP_VFRAG(v0__, (J_) * 4096);                                                                          \
+    vf10 = PP_VFRAG(v1__, (J_) * 4096);                                                                          \
+    vf01 = PP_VFRAG(v0__, (J_) * 4096 + 2048);                                                                   \
+    vf11 = PP_VFRAG(v1__, (J_) * 4096 + 2048);                                                                   \
+  } while (0)
+  // S = K Q^T from the K fragments in registers
+#define PP_SCORES(dst_)                                                                                          \
+  do {                                                                                                           \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[0], zero16, 0, 0, 0);                                 \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[1], dst_, 0, 0, 0);                                   \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf2, qf[2], dst_, 0, 0, 0);                                   \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf3, qf[3], dst_, 0, 0, 0);                                   \
+  } while (0)
+  // O^T += V^T P^T from the V fragments in registers, P in pf0, pf1
+#define PP_PV()                                                                                                  \
+  do {                                                                                                           \
+    o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf00, pf0, o_acc[0], 0, 0, 0);                            \
+    o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf10, pf0, o_acc[1], 0, 0, 0);                            \
+    o_acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf01, pf1, o_acc[0], 0, 0, 0);                            \
+    o_acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf11, pf1, o_acc[1], 0, 0, 0);                            \
+  } while (0)
+  // keys past the end of the sequence (only in the last tile, only when S is not a multiple of 64)
+#define PP_MASK(dst_, kt_, J_)                                                                                   \
+  do {                                                                                                           \
+    if ((kt_) == nkt - 1 && nkt * KB > S) {                                                                      \
+      _Pragma("unroll") for (int e__ = 0; e__ < 16; ++e__) {                                                     \
+        const int key__ = (kt_) * KB + (J_) * 32 + (e__ & 3) + 8 * (e__ >> 2) + 4 * h;                           \
+        if (key__ >= S) dst_[e__] = -INFINITY;                                                                   \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+  // row maximum of a score set over both lane halves
+#define PP_ROWMAX(c_)                                                                                            \
+  ({                                                                                                             \
+    float a__ = fmaxf(fmaxf(c_[0], c_[1]), c_[2]), b__ = fmaxf(fmaxf(c_[8], c_[9]), c_[10]);                     \
+    a__ = fmaxf(fmaxf(a__, c_[3]), c_[4]);                                                                       \
+    b__ = fmaxf(fmaxf(b__, c_[11]), c_[12]);                                                                     \
+    a__ = fmaxf(fmaxf(a__, c_[5]), c_[6]);                                                                       \
+    b__ = fmaxf(fmaxf(b__, c_[13]), c_[14]);                                                                     \
+    const float m2__ = fmaxf(fmaxf(a__, c_[7]), fmaxf(b__, c_[15]));                                             \
+    const auto sw__ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2__), __builtin_bit_cast(unsigned, m2__), false, false); \
+    fmaxf(__builtin_bit_cast(float, sw__[0]), __builtin_bit_cast(float, sw__[1]));                               \
+  })
+  // in place p = exp2(s - m) of elements 8 SP_ .. 8 SP_ + 7 of a score set, their sum added to acc_ (two partial sums), and P as
+  // a bf16 B fragment -> pa_
+#define PP_SOFTMAX8(c_, SP_, pa_, acc_)                                                                          \
+  do {                                                                                                           \
+    const f32x2 nm__ = {-m_run, -m_run};                                                                         \
+    _Pragma("unroll") for (int e__ = 8 * (SP_); e__ < 8 * (SP_) + (PP_KO_VALU ? 2 : 8); e__ += 2) {              \
+      const f32x2 x__ = (f32x2){c_[e__], c_[e__ + 1]} + nm__;                                                    \
+      c_[e__] = __builtin_amdgcn_exp2f(x__[0]);                                                                  \
+      c_[e__ + 1] = __builtin_amdgcn_exp2f(x__[1]);                                                              \
+      acc_ += (f32x2){c_[e__], c_[e__ + 1]};                                                                     \
+    }                                                                                                            \
+    pa_ = (bf16x8){(bf16_t)c_[8 * (SP_) + 0], (bf16_t)c_[8 * (SP_) + 1], (bf16_t)c_[8 * (SP_) + 2], (bf16_t)c_[8 * (SP_) + 3], \
+                   (bf16_t)c_[8 * (SP_) + 4], (bf16_t)c_[8 * (SP_) + 5], (bf16_t)c_[8 * (SP_) + 6], (bf16_t)c_[8 * (SP_) + 7]}; \
+  } while (0)
+  // rare path: the raw scores of half J_ of tile kt_ once more, K fragments straight from global memory (the exp2 ran in place,
+  // and for odd steps the tile's ring slot is already being refilled)
+#define PP_SCORES_AGAIN(dst_, kt_, J_)                                                                           \
+  do {                                                                                                           \
+    const int key__ = (kt_) * KB + (J_) * 32 + r;                                                                \
+    const bf16_t* kr__ = kbase + (size_t)(key__ < S ? key__ : S - 1) * ld + h * 8;                               \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr__), qf[0], zero16, 0, 0, 0); \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr__ + 16), qf[1], dst_, 0, 0, 0); \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr__ + 32), qf[2], dst_, 0, 0, 0); \
+    dst_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr__ + 48), qf[3], dst_, 0, 0, 0); \
+    PP_MASK(dst_, kt_, J_);                                                                                      \
+  } while (0)
+
+  // One step.  cur_ holds S(u) = scores of half CJ_ of tile ckt_; nxt_ receives S(u+1) (K fragments already in registers, tile
+  // nkt_ half NJ_); PV(u-1) uses the V fragments in registers.  PRE1_ / PRE2_: the fragment reads for later blocks, issued at the
+  // head of the first / second block.  Each block (4 MFMAs beside half of the softmax arithmetic of S(u)) is ONE basic block.
+  // P(u) and the row sum are pinned to it by the empty asm (they are consumed a step later: the compiler would sink the whole
+  // exp2 / pack sequence there, away from the MFMAs it is meant to run beside).
+#define PP_STEP(cur_, nxt_, FIRST_, PRE1_, PRE2_, NJ_, nkt_, ckt_, CJ_, SEG1_, SEG2_)                            \
+  do {                                                                                                           \
+    bf16x8 qa__, qb__;                                                                                           \
+    f32x2 acc__ = {0.f, 0.f};                                                                                    \
+    /* PV(u-1) beside the first 16 keys of the step */                                                           \
+    PRE1_;                                                                                                       \
+    if (!(FIRST_)) PP_PV();                                                                                      \
+    PP_SOFTMAX8(cur_, 0, qa__, acc__);                                                                           \
+    asm volatile("" : "+v"(qa__), "+v"(acc__));                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                        \
+      if (!(FIRST_)) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);                                                         \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    STAMP(SEG1_);                                                                                                \
+    /* S(u+1) beside the other 16 keys */                                                                        \
+    PRE2_;                                                                                                       \
+    PP_SCORES(nxt_);                                                                                             \
+    PP_SOFTMAX8(cur_, 1, qb__, acc__);                                                                           \
+    float ps__ = acc__[0] + acc__[1];                                                                            \
+    asm volatile("" : "+v"(qb__), "+v"(ps__));                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+      __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);                                                         \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    /* rare: a row sum beyond 2^defer_thr (or inf / nan): take the step's raw scores again, move the reference to their true */ \
+    /* maximum, rescale what was accumulated against the old one (PV(u-1) included) and redo the step's p                  */ \
+    if (__builtin_amdgcn_ballot_w64(!(ps__ <= p_limit)) != 0ull) {                                               \
+      PP_SCORES_AGAIN(cur_, ckt_, CJ_);                                                                          \
+      const float d__ = fmaxf(PP_ROWMAX(cur_) - m_run, 0.f);                                                     \
+      const float alpha__ = __builtin_amdgcn_exp2f(-d__);                                                        \
+      l_run *= alpha__;                                                                                          \
+      _Pragma("unroll") for (int dt__ = 0; dt__ < 2; ++dt__)                                                     \
+        _Pragma("unroll") for (int e__ = 0; e__ < 16; ++e__) o_acc[dt__][e__] *= alpha__;                        \
+      m_run += d__;                                                                                              \
+      acc__ = (f32x2){0.f, 0.f};                                                                                 \
+      PP_SOFTMAX8(cur_, 0, qa__, acc__);                                                                         \
+      PP_SOFTMAX8(cur_, 1, qb__, acc__);                                                                         \
+      ps__ = acc__[0] + acc__[1];                                                                                \
+    }                                                                                                            \
+    pf0 = qa__;                                                                                                  \
+    pf1 = qb__;                                                                                                  \
+    l_run += ps__;                                                                                               \
+    PP_MASK(nxt_, nkt_, NJ_);                                                                                    \
+    STAMP(SEG2_);                                                                                                \
+  } while (0)
+  // One tile t; o0, o1, o2: byte offsets of ring slots t % 3, (t+1) % 3, (t+2) % 3.  Entering: S(2t) in sA, P(2t-1) in pf, the
+  // fragments of V(t-1) half 1 in vf.  Steps 2t and 2t+1 with the tile's barrier / DMA hand-over between them:
+  //   block A1  reads K(t) half 1      | PV(2t-1)  beside softmax of S(2t)   keys 0-15
+  //   block A2                         | S(2t+1)   beside softmax of S(2t)   keys 16-31
+  //   wait, barrier, reads V(t) half 0 and K(t+1) half 0, DMA issue (its scalar work hides the LDS round trip)
+  //   block B1                         | PV(2t)    beside softmax of S(2t+1) keys 0-15
+  //   block B2  reads V(t) half 1      | S(2t+2)   beside softmax of S(2t+1) keys 16-31
+#define PP_TILE_STEPS(t_, FIRST_)                                                                                \
+  do {                                                                                                           \
+    const int tt__ = (t_);                                                                                       \
+    PP_STEP(sA, sB, FIRST_, PP_LOADK(o0, 1), (void)0, 1, tt__, tt__, 0, 0, 1);                                   \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     /* K(t+1), V(t) landed (own share); K(t+2), V(t+1) may fly */ \
+    STAMP(2);                                                                                                    \
+    if (!PP_KO_BARRIER) __builtin_amdgcn_s_barrier();    /* ... for every wave; all are done with K(t) and V(t-1) */ \
+    STAMP(3);                                                                                                    \
+    PP_LOADV(o0, 0);                                                                                             \
+    PP_LOADK(o1, 0);                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (PP_KO_DMA) {                                                                                             \
+    } else if (tt__ + 3 < nkt - 1) {                     /* K(t+3) -> slot of K(t), V(t+2) -> slot of V(t-1) */    \
+      const bf16_t* kp32__ = kdma + (size_t)32 * ld;                                                             \
+      const bf16_t* vp32__ = vdma + (size_t)32 * ld;                                                             \
+      PP_DMA4(kdma, kp32__, kl_lds + o0 + wave * 1024, vdma, vp32__, vl_lds + o2 + wave * 1024);                 \
+    } else {                                                                                                     \
+      PP_TILE(kbase, kl_lds, tt__ + 3, o0, kc, dK);                                                              \
+      PP_TILE(vbase, vl_lds, tt__ + 2, o2, vc, dV);                                                              \
+    }                                                                                                            \
+    kdma += (size_t)KB * ld;                                                                                     \
+    vdma += (size_t)KB * ld;                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    STAMP(4);                                                                                                    \
+    PP_STEP(sB, sA, false, (void)0, PP_LOADV(o0, 1), 0, tt__ + 1, tt__, 1, 5, 5);                                \
+  } while (0)
+
+  // ---- prologue: K(0) | V(0), K(1) | K(2), V(1) in flight (10 DMA instructions per wave); S(0) and its row maximum ----
+  PP_TILE(kbase, kl_lds, 0, 0, kc, dK);
+  PP_TILE(vbase, vl_lds, 0, 0, vc, dV);
+  PP_TILE(kbase, kl_lds, 1, KB * 128, kc, dK);
+  PP_TILE(kbase, kl_lds, 2, 2 * KB * 128, kc, dK);
+  PP_TILE(vbase, vl_lds, 1, KB * 128, vc, dV);
+  const bf16_t* kdma = kbase + (size_t)3 * KB * ld;      // K(t+3), V(t+2) for t = 0
+  const bf16_t* vdma = vbase + (size_t)2 * KB * ld;
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // K(0): this wave's share
+  __builtin_amdgcn_s_barrier();
+  PP_LOADK(0, 0);
+  PP_SCORES(sA);
+  PP_MASK(sA, 0, 0);
+  m_run = PP_ROWMAX(sA);
+  STAMP_DECL;
+  STAMP_START();
+#ifdef ATTN_STAMPS
+  const unsigned long long st_loop_start__ = st_prev__;
+#endif
+  {
+    int o0 = 0, o1 = KB * 128, o2 = 2 * KB * 128;      // ring slot byte offsets, rotated per tile (scalar registers)
+    PP_TILE_STEPS(0, true);
+    for (int t = 1; t < nkt; ++t) {
+      const int o = o0;
+      o0 = o1;
+      o1 = o2;
+      o2 = o;
+      PP_TILE_STEPS(t, false);
+    }
+  }
+  // ---- drain: PV(2 nkt - 1), half 1 of V(nkt-1): its fragments were read in the last block; sA holds scores of the re-fetched
+  // tile past the end: unused ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_PV();
+#ifdef ATTN_STAMPS
+  const unsigned long long st_loop_end__ = st_prev__;
+#endif
+#undef PP_TILE_STEPS
+#undef PP_STEP
+#undef PP_SCORES_AGAIN
+#undef PP_SOFTMAX8
+#undef PP_ROWMAX
+#undef PP_MASK
+#undef PP_PV
+#undef PP_SCORES
+#undef PP_LOADV
+#undef PP_VFRAG
+#undef PP_LOADK
+#undef PP_DMA4
+#undef PP_TILE
+#undef PP_DMA
+
+  // ---- normalise, gate, store (as k_attn_bf16) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = __builtin_amdgcn_rcpf(l_tot);
+  {
+    bf16_t* orow = out + (size_t)(s0 + qrc) * ldo + head * 64;
+    const bf16_t* grow = gbase + (size_t)qrc * ld;
+    const bool store = qrow < S;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        uint2 pk[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * gp + gg;
+          const int d0 = dt * 32 + 8 * g + 4 * h;
+          f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+          if (GATE) {
+            const f32x4 gt = Vec4<bf16_t>::load(grow + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gt[e] * -1.44269504088896340736f));
+          }
+          const bf16x4 b4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          pk[gg] = __builtin_bit_cast(uint2, b4);
+        }
+        const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const uint4 o16 = {sx[0], sy[0], sx[1], sy[1]};
+        if (store) *reinterpret_cast<uint4*>(orow + dt * 32 + 16 * gp + 8 * h) = o16;
+      }
+  }
+#ifdef ATTN_STAMPS
+  if (stamps && blockIdx.x % 37 == 0 && lane == 0) {      // [0..5] loop segments, [6] entry -> loop, [7] loop end -> stores issued
+    unsigned long long st_end__;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_end__)::"memory");
+    long long* dst = stamps + ((size_t)(blockIdx.x / 37) * 4 + wave) * 8;
+    for (int i = 0; i < 6; ++i) dst[i] = (long long)st_acc__[i];
+    dst[6] = (long long)(st_loop_start__ - st_entry__);
+    dst[7] = (long long)(st_end__ - st_loop_end__);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -779,7 +1198,15 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
   } while (0)
     const bool tape = lse_out != nullptr || out_raw != nullptr;
     TTV_CHECK_ARG(!tape || !prescaled, "attention: the training-tape outputs need unscaled q");
-    if (paired) {
+    // tables of full items only with pre-scaled q, no tape: the software-pipelined kernel on request (flag TTV_ATTN_PIPE; slower
+    // than the plain loop, see its header)
+    if ((flags & TTV_ATTN_PIPE) && (flags & TTV_ATTN_ALLFULL) && prescaled && !paired && !tape) {
+      // the reference moves when a lane's 16-key sum of p exceeds 2^pipe_thr: bf16 P and fp32 sums have the range for it, and
+      // with 40 the rare branch is rare for any score distribution (8, k_attn_bf16's value: every few tiles at a spread of 6)
+      static const float pipe_thr = getenv("TTV_ATTN_PIPE_THR") ? (float)atof(getenv("TTV_ATTN_PIPE_THR")) : ATTN_PIPE_THR;
+      if (gate_mul) hipLaunchKernelGGL((k_attn_pipe<true>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, pipe_thr, g_ttv_stamps);
+      else hipLaunchKernelGGL((k_attn_pipe<false>), grid, dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, pipe_thr, g_ttv_stamps);
+    } else if (paired) {
       // rows of 8 list slots; a block takes two consecutive rows of one slot
       const int rows = ttv_cdiv(n_qblocks, 8), pairs = ttv_cdiv(rows, 2);
       dim3 g2(pairs * 8);

@@ -173,6 +173,7 @@ class BatchPlan:
             blocks64=base + 4 * offs[4], row_seq=base + 4 * offs[5], n_blocks64=self.n_blocks64)
         self._offs = offs
         self._attn = {}
+        self._attn_all_full = {}
         self.reader_streams = {}
 
     def use_on_current_stream(self) -> None:
@@ -250,6 +251,7 @@ class BatchPlan:
             last = int(np.max(np.nonzero(flat[:, 0] >= 0)[0])) + 1
             t = _upload(np.ascontiguousarray(flat[:last]), self.device)
             self._attn[key] = t
+            self._attn_all_full[t.data_ptr()] = not bool((flat[:last, 3] > 0).any())
         return t
 
     def batch_for(self, q_heads: int, kv_heads: int) -> "_lib.Batch":
@@ -260,7 +262,8 @@ class BatchPlan:
         # (opt-in, TTV_ATTN_PAIRED=1: the 8-wave blocks halve the K/V tile traffic - +1.5 % with two batches in flight - but make
         # the grid coarser: the launch alone is 10 % slower)
         paired = 1 if (q_heads // kv_heads) % 2 == 0 and os.environ.get("TTV_ATTN_PAIRED", "0") == "1" else 0
-        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, **self._base_fields)
+        all_full = 1 if self._attn_all_full.get(t.data_ptr()) else 0
+        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full, **self._base_fields)
 
     # views used by tests that call single ops
     def table(self, i: int, n: int) -> torch.Tensor:

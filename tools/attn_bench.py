@@ -70,8 +70,13 @@ for spread in spreads:
     a = math.sqrt(spread / (8.0 * C_EXP))
     base[:, :dm] *= a
     base[:, 2 * dm:2 * dm + g] *= a
-    for dtype, name, flags, pre in ((torch.bfloat16, "bf16 gate", 1, False), (torch.bfloat16, "bf16 gate+qscaled", 1 | 4, True),
-                                    (torch.float32, "fp32 gate", 1, False)):
+    all_full = 8 if not bool((table[:, 3] > 0).any()) else 0
+    variants = [(torch.bfloat16, "bf16 gate", 1, False), (torch.bfloat16, "bf16 gate+qscaled", 1 | 4, True)]
+    if all_full:
+        variants.append((torch.bfloat16, "bf16 gate+qscaled pipe", 1 | 4 | 8 | 16, True))
+    if os.environ.get("FP32", "1") == "1":
+        variants.append((torch.float32, "fp32 gate", 1, False))
+    for dtype, name, flags, pre in variants:
         x = base.clone()
         if pre:
             x[:, :dm] *= C_EXP
@@ -81,5 +86,5 @@ for spread in spreads:
         err = max(float((out[b * S:(b + 1) * S].double() - r).abs().max()) for b, r in ref.items())
         rel = max(float((out[b * S:(b + 1) * S].double() - r).norm() / r.norm()) for b, r in ref.items())
         peak = 2500.0 if dtype == torch.bfloat16 else 157.3
-        print(f"spread {spread:4.1f} {name:20s} {us:8.1f} us  {flops / us / 1e6:8.1f} TFLOP/s = {flops / us / 1e6 / peak:.3f} of peak   "
+        print(f"spread {spread:4.1f} {name:24s} {us:8.1f} us  {flops / us / 1e6:8.1f} TFLOP/s = {flops / us / 1e6 / peak:.3f} of peak   "
               f"max abs err {err:.2e}  rel {rel:.2e}", flush=True)

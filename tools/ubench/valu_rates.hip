@@ -1,0 +1,165 @@
+// Issue cost of v_exp_f32 / v_add_f32 / v_cvt_pk_bf16_f32 / v_mfma_f32_32x32x16_bf16 for 1..4 waves per SIMD, alone and mixed:
+// cycles per instruction per wave and per SIMD (s_memtime around an unrolled loop).  Diagnostic; hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int KIND>
+__global__ void k(float* out, long long* cyc, int iters) {
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-3f + i;
+  f32x16 acc = {}, acc2 = {};
+  float w[16];
+  for (int i = 0; i < 16; ++i) w[i] = threadIdx.x * 2e-3f + i;
+  bf16x8 a = {}, b = {};
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.01f); b[i] = (__bf16)(i * 0.1f); }
+  long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (KIND == 0) v[i] = __builtin_amdgcn_exp2f(v[i]);
+      if (KIND == 1) v[i] = v[i] + 1.25f;
+      if (KIND == 2) { v[i] = __builtin_amdgcn_exp2f(v[i]); v[i] = v[i] + 1.25f; }
+      if (KIND == 3) { if (i % 4 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); v[i] = __builtin_amdgcn_exp2f(v[i]); }
+      if (KIND == 4) { if (i % 4 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); }
+      if (KIND == 5) v[i] = __builtin_amdgcn_rcpf(v[i]);
+      // the attention mix: per MFMA 6 plain + 2 exp2 (KIND 6: two accumulators alternate; 7: one dependent chain; 8: no exp2, 8 plain)
+      if (KIND == 6 || KIND == 7) {
+        if (i % 2 == 0) {
+          if (KIND == 6 && (i & 2)) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        v[i] = __builtin_amdgcn_exp2f(v[i]);                  // 1 exp2 + 3 plain per i, two i per MFMA
+        w[i] = w[i] + 1.25f;
+        w[(i + 5) & 15] = w[(i + 5) & 15] * 0.75f;
+        w[(i + 9) & 15] = w[(i + 9) & 15] + v[(i + 8) & 15];
+      }
+      if (KIND == 8) {
+        if (i % 2 == 0) {
+          if (i & 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        w[i] = w[i] + 1.25f;
+        w[(i + 5) & 15] = w[(i + 5) & 15] * 0.75f;
+        w[(i + 9) & 15] = w[(i + 9) & 15] + 0.5f;
+        w[(i + 13) & 15] = w[(i + 13) & 15] * 1.5f;
+      }
+      if (KIND == 9) {      // 2 accumulators, MFMA only
+        if (i % 2 == 0) {
+          if (i & 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (KIND >= 10) {
+    // phase structure of an attention tile, no in-wave interleave: 16 MFMAs (two accumulators), then 96 plain + 32 exp2
+    // (KIND 10), or 96 plain only (11), or the MFMAs only (12): do co-resident waves overlap each other's phases?
+    for (int it = 0; it < iters; ++it) {
+      if (KIND != 13) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (KIND != 12) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (KIND != 11) v[i] = __builtin_amdgcn_exp2f(v[i]);
+            w[i] = w[i] + 1.25f;
+            w[(i + 5) & 15] = w[(i + 5) & 15] * 0.75f;
+            w[(i + 9) & 15] = w[(i + 9) & 15] + 0.5f;
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (KIND >= 20) {
+    // the non-ALU ingredients of an attention tile, per iteration: 20 = 8 ds_read_b128 + 16 ds_read_b64 (consumed by a cheap xor),
+    // 21 = 64 dependent s_add, 22 = 4 global_load_lds_dwordx4 (1 KiB each, L2-resident source) with a counted wait,
+    // 23 = one s_barrier, 24 = 8 untaken branches on a VALU compare (v_cmp + s_cbranch_vccnz)
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    unsigned sacc = iters;
+    unsigned vx = 0;
+    for (int it = 0; it < iters; ++it) {
+      if (KIND == 20) {
+        const char* p0 = smem + (threadIdx.x & 63) * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint4 q = *reinterpret_cast<const uint4*>(p0 + i * 1024 + (it & 1) * 8192); vx ^= q.x ^ q.w; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const uint2 q = *reinterpret_cast<const uint2*>(p0 + i * 1024 + 16384 + (it & 1) * 8); vx ^= q.x ^ q.y; }
+      }
+      if (KIND == 21) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sacc) : "s"(it) : "scc");
+      }
+      if (KIND == 22) {
+        const unsigned voff = (threadIdx.x & 63) * 16;
+        const float* src = out + (blockIdx.x & 63) * 4096 + (it & 3) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (threadIdx.x >> 6) * 4096 + i * 1024);
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff + i * 1024), "s"(src), "s"(dst) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      if (KIND == 23) __builtin_amdgcn_s_barrier();
+      if (KIND == 24) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (__builtin_amdgcn_ballot_w64(v[i] > 1e30f) != 0ull) { v[i] = __builtin_amdgcn_exp2f(v[i]); vx += 1; }
+          v[i] = v[i] * 0.999f;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    v[0] += (float)(vx + sacc);
+  }
+  long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc2[i] + w[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x % 64 == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char* name, int per_iter) {
+  float* out; long long* cyc;
+  hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8192 * 8);
+  for (int wps = 1; wps <= 4; ++wps) {      // waves per SIMD: block of 256*wps threads, one block per CU
+    const int threads = 256 * wps, iters = 200;
+    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+    hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    std::vector<long long> h(256 * threads / 64);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double s = 0; for (auto c : h) s += c; s /= h.size();
+    printf("%-28s %d waves/SIMD: %.1f cycles per instruction per wave, %.1f per SIMD\n", name, wps, s / (iters * per_iter), s / (iters * per_iter * wps));
+  }
+}
+int main() {
+  run<0>("v_exp_f32", 16); run<1>("v_add_f32", 16); run<5>("v_rcp_f32", 16); run<2>("v_exp + v_add (pairs)", 32);
+  run<4>("mfma 32x32x16 alone", 4); run<3>("4 v_exp per mfma (count exp)", 16);
+  run<9>("mfma, 2 accumulators (per mfma)", 8);
+  run<6>("mfma + 6 plain + 2 exp2, 2 acc (per mfma)", 8);
+  run<7>("mfma + 6 plain + 2 exp2, 1 acc (per mfma)", 8);
+  run<8>("mfma + 8 plain, 2 acc (per mfma)", 8);
+  run<20>("8 ds_read_b128 + 16 ds_read_b64 (per iteration)", 1);
+  run<21>("64 s_add (per iteration)", 1);
+  run<22>("4 global_load_lds_dwordx4 (per iteration)", 1);
+  run<23>("s_barrier (per iteration)", 1);
+  run<24>("8 x (v_cmp, untaken branch, v_mul) (per iteration)", 1);
+  run<12>("phase: 16 mfma (per iteration)", 1);
+  run<13>("phase: 96 plain + 32 exp2 (per iteration)", 1);
+  run<11>("phases: 16 mfma | 96 plain (per iteration)", 1);
+  run<10>("phases: 16 mfma | 96 plain + 32 exp2 (per iteration)", 1);
+  return 0;
+}
