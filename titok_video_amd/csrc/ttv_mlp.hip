@@ -110,12 +110,14 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 cvt4(bf16x4 b) { return (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]}; }
 #define MLP_LD12(img_, t_, s8_)                                                                                    \
   __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
-#define MLP_GLDS16(chunk_, ldsaddr_)   /* copies 64 uint4 starting at p.pack[chunk_] (wave-uniform) to LDS byte address ldsaddr_ */ \
+#define MLP_GLDS16(src_, i_, ldsaddr_)   /* copies 64 uint4 starting at src_[512 i_] (wave-uniform) to LDS byte address ldsaddr_ */ \
   do {                                                                                                             \
     unsigned keep__;                                                                                               \
-    const uint32_t voff__ = lane16 + (uint32_t)(chunk_) * 16u;                                                     \
+    /* scalar base per image + four per-lane offsets (lane * 16 + 8192 i) shared by every copy of the kernel: with the whole   */ \
+    /* chunk index in the vector offset the compiler kept a dozen loop-invariant offset registers alive and spilled around the */ \
+    /* 256-VGPR loop; with it in precomputed scalar bases it ran out of SGPRs instead                                           */ \
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep__) : "v"(voff__), "s"(p.pack), "s"(ldsaddr_) : "memory");                             \
+                 : "=&s"(keep__) : "v"(lane16 + (uint32_t)(i_) * 8192u), "s"(src_), "s"(ldsaddr_) : "memory");      \
   } while (0)
 #define MLP_STAMP()                                                                                                \
   do {                                                                                                             \
@@ -138,15 +140,15 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   const uint32_t lds_l3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)l3;
 #define GLDS_W12(pn_, buf_)                                                                                        \
   do {                                                                                                             \
-    const int src__ = (pn_) * MLP_PANEL_CHUNKS + wave * 64;                                                        \
+    const uint4* src__ = p.pack + ((size_t)(pn_) * MLP_PANEL_CHUNKS + wave * 64);                                  \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
   } while (0)
 #define GLDS_W3(pn_, buf_)                                                                                         \
   do {                                                                                                             \
-    const int src__ = (pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64;                                       \
+    const uint4* src__ = p.pack + ((size_t)(pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64);                 \
     const uint32_t dst__ = lds_l3 + ((buf_) * MLP_W3_CHUNKS + wave * 64) * 16;                                     \
-    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
+    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
   } while (0)
 
   const int tok0 = tile * (64 * NT) + w4 * (16 * NT) + l15;   // token of tile j: tok0 + 16 j
@@ -167,9 +169,9 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     // tokens in C layout, which IS the B-fragment layout above); Wo streams through the W12 buffers as 4 panel images ----
 #define GLDS_WO(wp_, buf_)                                                                                         \
   do {                                                                                                             \
-    const int src__ = np * MLP_PANEL_CHUNKS + (wp_) * MLP_W12_CHUNKS + wave * 64;                                  \
+    const uint4* src__ = p.pack + ((size_t)np * MLP_PANEL_CHUNKS + (wp_) * MLP_W12_CHUNKS + wave * 64);            \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
   } while (0)
     GLDS_WO(0, 0);
     bf16x8 abf[T1A][8];
@@ -214,13 +216,12 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     }
 #undef GLDS_WO
     GLDS_W12(0, 0);
-    // residual, row statistics, gain; the bf16-rounded x' goes to y (residual of the P2 owner's epilogue) and, as is,
-    // into the B fragments of phase 1
+    // residual, row statistics, gain; the bf16-rounded x' becomes the B fragments of phase 1, and after the panel loop the very
+    // same registers are handed to the P2 owner through LDS as the residual of its epilogue (x' never goes to global memory)
 #pragma unroll
     for (int j = 0; j < T1; ++j) {
       const int t = tok0 + 16 * (P1F + j);
-      const bool tv = t < p.M;
-      const int tc = tv ? t : p.M - 1;
+      const int tc = t < p.M ? t : p.M - 1;
       // scalar base + 32-bit per-lane byte offsets everywhere below: 64-bit row pointers in VGPRs get spilled in this kernel
       // and every scratch reload comes with a vmcnt(0) that serialises the stores / drains the LDS-DMA in flight
       const uint32_t roff = ((uint32_t)tc * (uint32_t)p.ldx + kq * 4) * 2u;
@@ -237,7 +238,6 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
         ss += __shfl_xor(ss, 32, 64);
         scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
       }
-      const uint32_t yoff = ((uint32_t)tc * (uint32_t)p.ldy + kq * 4) * 2u;
       float ss2 = 0.f;
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
@@ -257,7 +257,6 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
             const float r = (float)q[u][e];
             ss2 = fmaf(r, r, ss2);
           }
-          if (tv) *(__attribute__((address_space(1))) u32x2_t*)(gy + yoff + m * 32) = __builtin_bit_cast(u32x2_t, q[u]);
         }
         bfr[j][s8] = (bf16x8){q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3]};
       }
@@ -413,6 +412,19 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   }
   MLP_STAMP();
 
+  // ---- FRONT: hand the x' rows of the P1 tiles to their P2 owners.  The weight images are dead after the loop's last barrier and
+  // the 96 KiB they occupied hold exactly the 4 x NT token tiles of the block at 8 KiB each; a lane of the P2 wave needs, for the
+  // m-tiles 2 s8 and 2 s8 + 1, the very 8 values the same lane of the P1 wave holds in bfr[.][s8] (the C layout of the second
+  // product IS the B-fragment layout of the first): one 16-byte vector per (tile, s8), lane to same lane, no conflicts. ----
+  uint4* const xres = l12;      // [4 wave pairs][NT][8][64 lanes]; l3 follows l12 in the block's LDS
+  if (FRONT) {
+#pragma unroll
+    for (int j = 0; j < T1; ++j)
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) xres[((w4 * NT + P1F + j) * 8 + s8) * 64 + lane] = __builtin_bit_cast(uint4, bfr[j][s8]);
+    __syncthreads();
+  }
+
   // ---- epilogue of the P2 tiles: y = alpha*x + acc ; x_new = KEEL ? RMSNorm(y)*gain : y ----
   bf16x8 xq[T2A][8];
   float rstdq[T2A];
@@ -421,24 +433,27 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     const int t = tok0 + 16 * (P2F + j);
     const bool tv = t < p.M;
     const int tc = tv ? t : p.M - 1;
-    // FRONT: the residual is the x' its partner wave stored to y during the prologue - read at agent scope (L2), not
-    // through this CU's L1.  Scalar base + 32-bit byte offsets (see the front).
-    const uint32_t roff = FRONT ? ((uint32_t)tc * (uint32_t)p.ldy + kq * 4) * 2u : ((uint32_t)tc * (uint32_t)p.ldx + kq * 4) * 2u;
+    // FRONT: the residual is the x' its partner wave left in LDS; otherwise the input rows (scalar base + 32-bit byte offsets)
+    const uint32_t roff = ((uint32_t)tc * (uint32_t)p.ldx + kq * 4) * 2u;
     float ss = 0.f;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      f32x4 rv;
+    for (int s8 = 0; s8 < 8; ++s8) {
+      f32x4 rv0, rv1;
       if (FRONT) {
-        const uint64_t raw = __hip_atomic_load((const __attribute__((address_space(1))) uint64_t*)(gy + roff + m * 32),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bf16x4 rb = __builtin_bit_cast(bf16x4, raw);
-        rv = (f32x4){(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+        const bf16x8 rb = __builtin_bit_cast(bf16x8, xres[((w4 * NT + P2F + j) * 8 + s8) * 64 + lane]);
+        rv0 = (f32x4){(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+        rv1 = (f32x4){(float)rb[4], (float)rb[5], (float)rb[6], (float)rb[7]};
       } else {
-        rv = cvt4(*(const __attribute__((address_space(1))) bf16x4*)(gx + roff + m * 32));
+        rv0 = cvt4(*(const __attribute__((address_space(1))) bf16x4*)(gx + roff + (2 * s8) * 32));
+        rv1 = cvt4(*(const __attribute__((address_space(1))) bf16x4*)(gx + roff + (2 * s8 + 1) * 32));
       }
-      out[m][j] += p.alpha * rv;
+      out[2 * s8][j] += p.alpha * rv0;
+      out[2 * s8 + 1][j] += p.alpha * rv1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ss = fmaf(out[m][j][e], out[m][j][e], ss);
+      for (int e = 0; e < 4; ++e) {
+        ss = fmaf(out[2 * s8][j][e], out[2 * s8][j][e], ss);
+        ss = fmaf(out[2 * s8 + 1][j][e], out[2 * s8 + 1][j][e], ss);
+      }
     }
     float scale = 1.0f;
     if (KEEL) {
@@ -492,10 +507,11 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     // Explicitly-global row pointers + immediates, as everywhere in this kernel. ----
 #define GLDS_WQ(qp_, buf_)                                                                                         \
   do {                                                                                                             \
-    const int src__ = np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + (qp_) * MLP_W12_CHUNKS + wave * 64;                  \
+    const uint4* src__ = p.pack + ((size_t)np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + (qp_) * MLP_W12_CHUNKS + wave * 64); \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__ + i__ * 512, dst__ + i__ * 8192);         \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
   } while (0)
+    __syncthreads();      // every wave has read its residuals out of the image buffers
     GLDS_WQ(0, 0);
     gchar* const gq = (gchar*)p.qkv;
     gcchar* const grope = (gcchar*)p.rope_cs;
@@ -596,10 +612,11 @@ __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: DMA bases / role branch stay in SGPRs
   constexpr int TA = NT - NT / 2;   // P1 tiles of the first wave of a pair (2 of 3, 1 of 2)
   int n_stamp = 0;
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
-    else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
-  }
+  // one tile per block (grid = n_tiles; with more tiles than CUs the dispatcher queues the rest - one block fits a CU): inside a
+  // persistent tile loop the compiler hoisted lane constants of every phase to the top and spilled them around the 256-VGPR body
+  const int tile = blockIdx.x;
+  if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
+  else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
 }
 #undef MLP_LD12
 #undef MLP_GLDS16
@@ -658,7 +675,7 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
   if (g_ttv_debug & 8) nt = 2;     // debug bit3 forces the 2-tile variant
   if (g_ttv_debug & 64) nt = 1;    // debug bit6 forces the 1-tile variant
   d.n_tiles = ttv_cdiv(M, 64 * nt);
-  const int grid = d.n_tiles < cus ? d.n_tiles : cus;
+  const int grid = d.n_tiles;
   const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4) + 2048;   // 96 KiB + 8 KiB per token tile + gains
   TtvProfScope prof(TTV_KC_GEMM_GEGLU, s);
 #define LAUNCH_MLP(NT_, KEEL_, FRONT_, BACK_)                                                                       \
