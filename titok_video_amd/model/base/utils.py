@@ -2,7 +2,8 @@
 
 Mirrors the interface of the reference's model/base/utils.py (get_model_dims 8-23, init_weights
 54-66).  The reference's einops patch/unpatch helpers (26-51) have no host counterpart here: the
-rearrangement runs inside the HIP patch-gather / patch-scatter kernels (csrc/ttv_patch.hip).
+rearrangement runs inside the proj_in / proj_out GEMM kernels (csrc/ttv_gemm.hip: k_gemm_bf16<STORE, GATHER>, k_gemm_k256<STORE_PATCH>)
+or, for other patch shapes / dtypes, in k_patch_copy (csrc/ttv_elem.hip).
 """
 from __future__ import annotations
 
