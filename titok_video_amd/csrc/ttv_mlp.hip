@@ -110,20 +110,46 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 cvt4(bf16x4 b) { return (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]}; }
 #define MLP_LD12(img_, t_, s8_)                                                                                    \
   __builtin_bit_cast(bf16x8, (img_)[((t_) * 16 + l15) * 32 + ((((s8_) * 4 + kq) & 16) | ((((s8_) * 4 + kq) & 15) ^ l15))])
-#define MLP_GLDS16(src_, i_, ldsaddr_)   /* copies 64 uint4 starting at src_[512 i_] (wave-uniform) to LDS byte address ldsaddr_ */ \
+// LDS-DMA of 1 KiB pieces of a packed image: piece i_ = 64 uint4 starting at src_[512 i_] (wave-uniform) -> LDS byte address
+// dst_ + 8192 i_.  Scalar base per image + one per-lane offset register (lane * 16, the piece offset added per instruction from four
+// loop-invariant registers): with the whole chunk index in the vector offset the compiler kept a dozen loop-invariant offset registers
+// alive and spilled around the 256-VGPR loop; with it in precomputed scalar bases it ran out of SGPRs instead.  All pieces of an image
+// go out in ONE statement: M0 is saved and restored once, not per piece.
+#define MLP_GLDS_4(src_, dst_)                                                                                     \
   do {                                                                                                             \
     unsigned keep__;                                                                                               \
-    /* scalar base per image + four per-lane offsets (lane * 16 + 8192 i) shared by every copy of the kernel: with the whole   */ \
-    /* chunk index in the vector offset the compiler kept a dozen loop-invariant offset registers alive and spilled around the */ \
-    /* 256-VGPR loop; with it in precomputed scalar bases it ran out of SGPRs instead                                           */ \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep__) : "v"(lane16 + (uint32_t)(i_) * 8192u), "s"(src_), "s"(ldsaddr_) : "memory");      \
+    asm volatile("s_mov_b32 %0, m0\n\t"                                                                            \
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"                               \
+                 "s_add_u32 m0, %6, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"                       \
+                 "s_add_u32 m0, %6, 0x4000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"                       \
+                 "s_add_u32 m0, %6, 0x6000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"                       \
+                 "s_mov_b32 m0, %0"                                                                                \
+                 : "=&s"(keep__)                                                                                   \
+                 : "v"(lane16), "v"(lane16 + 8192u), "v"(lane16 + 16384u), "v"(lane16 + 24576u), "s"(src_), "s"(dst_) \
+                 : "memory", "scc");                                                                               \
   } while (0)
+#define MLP_GLDS_2(src_, dst_)                                                                                     \
+  do {                                                                                                             \
+    unsigned keep__;                                                                                               \
+    asm volatile("s_mov_b32 %0, m0\n\t"                                                                            \
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"                               \
+                 "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"                       \
+                 "s_mov_b32 m0, %0"                                                                                \
+                 : "=&s"(keep__)                                                                                   \
+                 : "v"(lane16), "v"(lane16 + 8192u), "s"(src_), "s"(dst_)                                          \
+                 : "memory", "scc");                                                                               \
+  } while (0)
+// in-kernel stamps exist in the diagnostic build only (-DMLP_STAMPS, tools/attn_stamps.sh builds it into libtitok_hip_stamps.so for
+// tools/mlp_ablate.py): in the product build they cost two s_memtime, a compare / saveexec / branch each per panel iteration
+#ifdef MLP_STAMPS
 #define MLP_STAMP()                                                                                                \
   do {                                                                                                             \
     if (p.stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && n_stamp < 64)                               \
       p.stamps[(wave >> 2) * 64 + n_stamp++] = (long long)__builtin_readcyclecounter();                            \
   } while (0)
+#else
+#define MLP_STAMP() do { (void)n_stamp; } while (0)
+#endif
 
 // One wave's share of one 64*NT-token tile: P1 of token tiles [P1F, P1F+T1), P2 of token tiles [P2F, P2F+NT-T1).
 template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL, bool FRONT, bool BACK>
@@ -142,13 +168,13 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   do {                                                                                                             \
     const uint4* src__ = p.pack + ((size_t)(pn_) * MLP_PANEL_CHUNKS + wave * 64);                                  \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
+    MLP_GLDS_4(src__, dst__);                                                                                      \
   } while (0)
 #define GLDS_W3(pn_, buf_)                                                                                         \
   do {                                                                                                             \
     const uint4* src__ = p.pack + ((size_t)(pn_) * MLP_PANEL_CHUNKS + MLP_W12_CHUNKS + wave * 64);                 \
     const uint32_t dst__ = lds_l3 + ((buf_) * MLP_W3_CHUNKS + wave * 64) * 16;                                     \
-    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
+    MLP_GLDS_2(src__, dst__);                                                                                      \
   } while (0)
 
   const int tok0 = tile * (64 * NT) + w4 * (16 * NT) + l15;   // token of tile j: tok0 + 16 j
@@ -171,7 +197,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   do {                                                                                                             \
     const uint4* src__ = p.pack + ((size_t)np * MLP_PANEL_CHUNKS + (wp_) * MLP_W12_CHUNKS + wave * 64);            \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
+    MLP_GLDS_4(src__, dst__);                                                                                      \
   } while (0)
     GLDS_WO(0, 0);
     bf16x8 abf[T1A][8];
@@ -509,7 +535,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   do {                                                                                                             \
     const uint4* src__ = p.pack + ((size_t)np * MLP_PANEL_CHUNKS + MLP_WO_CHUNKS + (qp_) * MLP_W12_CHUNKS + wave * 64); \
     const uint32_t dst__ = lds_l12 + ((buf_) * MLP_W12_CHUNKS + wave * 64) * 16;                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) MLP_GLDS16(src__, i__, dst__ + i__ * 8192);                \
+    MLP_GLDS_4(src__, dst__);                                                                                      \
   } while (0)
     __syncthreads();      // every wave has read its residuals out of the image buffers
     GLDS_WQ(0, 0);
@@ -619,7 +645,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
   else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
 }
 #undef MLP_LD12
-#undef MLP_GLDS16
+#undef MLP_GLDS_4
+#undef MLP_GLDS_2
 #undef MLP_STAMP
 
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner) { return dtype == TTV_BF16 && width == 256 && inner % 32 == 0 && inner > 0; }
