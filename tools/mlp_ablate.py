@@ -1,3 +1,5 @@
+# In-kernel stamps of the layer-tail kernel.  Needs the diagnostic build:
+#   bash tools/attn_stamps.sh && TTV_LIB_PATH=titok_video_amd/csrc/build/libtitok_hip_stamps.so python tools/mlp_ablate.py
 import os, sys, torch, ctypes as C
 sys.path.insert(0, os.getcwd())
 from titok_video_amd import _lib
