@@ -321,6 +321,48 @@ def test_training_step_updates_weights_like_reference():
         assert rel(p.detach(), r.detach()) < 1e-5, n
 
 
+def test_mixed_precision_training_step_fp32_master_weights_bf16_compute():
+    """The reference trains bf16-mixed (fp32 parameters, bf16 autocast).  Here the compute dtype of a tower is the dtype of the
+    clips it is given and the weight pack holds compute-dtype copies of the parameters, so fp32 parameters + bf16 clips IS that mode:
+    the forward / backward run on the bf16 kernels, the gradients arrive in fp32 on the fp32 parameters, and an update far below
+    bf16 resolution is kept by the master weights."""
+    from titok_video_amd.train import make_optimizer, training_step
+    shapes, counts = [(4, 16, 16), (8, 32, 48), (4, 8, 24)], [2, 5, 3]
+    model = TiTok(config())
+    model.load_state_dict(seeded_titok_state(0), strict=True)
+    model = model.to(DEV).train()                                     # fp32 master weights
+    assert all(p.dtype == torch.float32 for p in model.parameters())
+    clips = synthetic_clips(shapes, seed=31, dtype=torch.bfloat16, device=DEV)
+    # same step with pure-bf16 parameters: the kernels see the same bf16 weight copies, so the gradients must agree closely
+    ref = TiTok(config())
+    ref.load_state_dict(seeded_titok_state(0), strict=True)
+    ref = ref.to(DEV, torch.bfloat16).train()
+    for m in (model, ref):
+        recon, out = m(clips, counts)
+        assert recon[0].dtype == torch.bfloat16
+        from titok_video_amd.train import l1_reconstruction_loss
+        l1_reconstruction_loss(recon, [c * 0.5 for c in clips]).backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), n
+        g, h = p.grad.double().flatten(), q.grad.double().flatten()
+        if float(h.norm()) > 0 and p.numel() >= 4096:
+            # not bit-equal by construction: the bf16 model rounds norm gains, biases and the gradients themselves to bf16, and a
+            # token whose index flips between the two runs legitimately changes the decoder's input (cf. the per-tower tests above)
+            assert float((g @ h) / (g.norm() * h.norm() + 1e-30)) > 0.9, n
+    # one optimizer step with a learning rate whose update (~1e-7 relative) a bf16 parameter could not represent
+    for m in (model, ref):
+        m.zero_grad(set_to_none=True)
+    opt = make_optimizer(model, lr=1e-7, weight_decay=0.0)
+    before = [p.detach().clone() for p in model.parameters()]
+    loss, gnorm, idx = training_step(model, clips, counts, opt, target=[c * 0.5 for c in clips])
+    assert torch.isfinite(loss) and torch.isfinite(gnorm) and idx.numel() == sum(counts)
+    moved = sum(int((a != p.detach()).sum()) for a, p in zip(before, model.parameters()))
+    total = sum(p.numel() for p in model.parameters())
+    assert moved > 0.5 * total, (moved, total)                          # fp32 masters keep the 1e-7 update
+    worst = max(float((a - p.detach()).abs().max()) for a, p in zip(before, model.parameters()))
+    assert worst < 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_l1_loss_matches_autograd(dt):
