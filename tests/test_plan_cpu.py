@@ -60,8 +60,12 @@ def test_attention_table_half_items_for_small_grids_only():
     one = one[one[:, 0] >= 0]
     mine = real[real[:, 0] == 7][:, 1:]
     assert sorted(map(tuple, mine.tolist())) == sorted(map(tuple, one[:, 1:].tolist()))   # same items alone and in the batch
-    big = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu").attention_table(4, 2)
+    big_plan = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu")
+    big = big_plan.attention_table(4, 2)
     assert int((big[:, 3] == 1).sum()) == 0 and int((big[:, 0] >= 0).sum()) == 1152
+    # ttv_batch.qblocks_all_full (attention flag TTV_ATTN_ALLFULL) follows the table actually handed to the library
+    assert big_plan.batch_for(4, 2).qblocks_all_full == 1
+    assert plan.batch_for(4, 2).qblocks_all_full == 0
 
 
 def test_plan_rope_table_is_reference_bits():
