@@ -321,6 +321,36 @@ def test_training_step_updates_weights_like_reference():
         assert rel(p.detach(), r.detach()) < 1e-5, n
 
 
+def test_graphed_training_step_replays_the_eager_step():
+    """GraphedTrainingStep: the HIP-graph replay of a training step leaves the parameters where the eager step leaves them (three
+    steps each, fresh optimizers, same clips; bf16: the norm-gain gradients accumulate with fp32 atomics, hence a tolerance)."""
+    from titok_video_amd.train import GraphedTrainingStep, make_optimizer, training_step
+    shapes, counts = [(4, 16, 16), (8, 32, 48), (4, 8, 24)], [2, 5, 3]
+    clips = synthetic_clips(shapes, seed=31, dtype=torch.bfloat16, device=DEV)
+
+    def fresh():
+        m = TiTok(config())
+        m.load_state_dict(seeded_titok_state(0), strict=True)
+        return m.to(DEV).train()                                      # fp32 master weights, bf16 compute
+    eager, graphed = fresh(), fresh()
+    opt_e = make_optimizer(eager, lr=1e-3, capturable=True)
+    opt_g = make_optimizer(graphed, lr=1e-3, capturable=True)
+    step = GraphedTrainingStep(graphed, opt_g, clips, counts)
+    for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert torch.equal(p, q), n                                   # the capture's warm-up steps were undone
+    losses = []
+    for _ in range(3):
+        le, _, ie = training_step(eager, clips, counts, opt_e)
+        lg, _, ig = step(clips)
+        losses.append((float(le), float(lg)))
+        assert torch.equal(ie, ig)
+    for le, lg in losses:
+        assert abs(le - lg) < 2e-3 * abs(le), losses
+    assert losses[2][0] < losses[0][0]                                # it trains
+    for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert float((p - q).detach().abs().max()) < 2e-3 * max(1.0, float(p.detach().abs().max())), n
+
+
 def test_mixed_precision_training_step_fp32_master_weights_bf16_compute():
     """The reference trains bf16-mixed (fp32 parameters, bf16 autocast).  Here the compute dtype of a tower is the dtype of the
     clips it is given and the weight pack holds compute-dtype copies of the parameters, so fp32 parameters + bf16 clips IS that mode:

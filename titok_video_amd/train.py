@@ -60,11 +60,13 @@ def freeze_python_gc() -> None:
     gc.freeze()
 
 
-def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.96, weight_decay: float = 1e-4):
-    """AdamW with the reference's hyper-parameters (configs/tiny.yaml:39-46, train.py:170-190)."""
+def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.96, weight_decay: float = 1e-4,
+                   capturable: bool = False):
+    """AdamW with the reference's hyper-parameters (configs/tiny.yaml:39-46, train.py:170-190).  capturable=True keeps the step
+    counter on the device so that the step can be recorded into a HIP graph (GraphedTrainingStep)."""
     params = [p for p in model.parameters() if p.requires_grad]
     fused = bool(params) and all(p.is_cuda for p in params)      # one multi-tensor kernel instead of a launch per parameter
-    return torch.optim.AdamW(params, lr=lr, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused)
+    return torch.optim.AdamW(params, lr=lr, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused, capturable=capturable and fused)
 
 
 def _reducer_for(model, group, overlap: bool):
@@ -116,6 +118,66 @@ def training_step(model, clips: List[torch.Tensor], token_counts, optimizer, max
     gnorm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     optimizer.step()
     return loss.detach(), gnorm, out["indices"]
+
+
+class GraphedTrainingStep:
+    """One generator training step (training_step: forward with tape, L1, backward, clip, AdamW) recorded ONCE into a HIP graph for a
+    fixed batch shape and replayed per step ("HIP-graph capture of the training step").
+
+    The tower entry points only enqueue kernels on the current stream (no allocation, no synchronisation inside the library), plans
+    and weight packs are built during the warm-up steps, and the pack refresh after each optimizer step (parameter version -> new
+    compute-dtype copies) is part of the captured sequence, so a replay is exact.  Constraints: one batch shape per instance (clip
+    shapes and token counts fixed; ragged token-budget batches need one instance per shape signature), an optimizer created with
+    capturable=True, single process (the overlapped DP reducer launches collectives from Python callbacks).
+
+    Measured (tools/bench_train.py GRAPH=1): the replay runs at the speed of the eager step, 3.48 ms at 5 clips and 8.1 ms at 32 -
+    with the Python garbage collector frozen the host issues the ~300 launches of a step faster than the GPU runs them (3.6 ms of
+    kernel time at 5 clips: the small kernels are latency-bound at ~12 us each), so on this stack a graph buys nothing; what would
+    is fewer launches.  Kept as a tested utility for hosts that ARE issue-bound.
+
+        step = GraphedTrainingStep(model, opt, example_clips, counts)
+        loss, grad_norm, indices = step(clips)          # copies the clips into the graph's input buffers, replays"""
+
+    def __init__(self, model, optimizer, example_clips, token_counts, max_grad_norm: float = 1.0, warmup: int = 3):
+        import copy
+        dev = next(model.parameters()).device
+        self.model, self.optimizer, self.counts = model, optimizer, list(token_counts)
+        self.inputs = [c.detach().clone() for c in example_clips]
+        params = [p for p in model.parameters()]
+        saved_params = [p.detach().clone() for p in params]
+        saved_opt = copy.deepcopy(optimizer.state_dict())          # empty state for a fresh optimizer
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                   # warm-up on the capture stream: plans, packs, optimizer state, allocator pool
+            for _ in range(warmup):
+                training_step(model, self.inputs, self.counts, optimizer, max_grad_norm, overlap=False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(self.graph, stream=side):
+            self.loss, self.gnorm, self.indices = training_step(model, self.inputs, self.counts, optimizer, max_grad_norm, overlap=False)
+        # the warm-up steps trained on the example batch: put parameters and optimizer state back IN PLACE (the graph holds their
+        # addresses); a fresh optimizer goes back to zero moments and step 0
+        with torch.no_grad():
+            for p, q in zip(params, saved_params):
+                p.copy_(q)
+            old = saved_opt["state"]
+            for i, p in enumerate(optimizer.param_groups[0]["params"]):
+                st = optimizer.state.get(p, {})
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if i in old and k in old[i]:
+                            v.copy_(old[i][k])
+                        else:
+                            v.zero_()
+        for mod in model.modules():                     # the packed copies were made from the warm-up weights
+            if hasattr(mod, "invalidate_packs"):
+                mod.invalidate_packs()
+
+    def __call__(self, clips):
+        torch._foreach_copy_(self.inputs, list(clips))
+        self.graph.replay()
+        return self.loss, self.gnorm, self.indices
 
 
 def make_discriminator_optimizer(loss_module: torch.nn.Module, lr: float = 1e-4, disc_lr_ratio: float = 0.15, beta1: float = 0.5,
