@@ -151,13 +151,13 @@ __device__ __forceinline__ f32x4 cvt4(bf16x4 b) { return (f32x4){(float)b[0], (f
 #define MLP_STAMP() do { (void)n_stamp; } while (0)
 #endif
 
-// One wave's share of one 64*NT-token tile: P1 of token tiles [P1F, P1F+T1), P2 of token tiles [P2F, P2F+NT-T1).
-template <int NT, int T1, int P1F, int P2F, bool GELU_FIRST, bool KEEL, bool FRONT, bool BACK>
+// One wave's share of one block of TPB 16-token tiles (block-global tile indices): P1 of tiles [P1F, P1F+T1), P2 of tiles
+// [P2F, P2F+T2).  P1F / P2F are wave-uniform run-time values: waves with the same (T1, T2) share one instantiation.
+template <int TPB, int T1, int T2, bool GELU_FIRST, bool KEEL, bool FRONT, bool BACK>
 __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3, uint4* hb, const float* gl, int tile, int wave, int lane,
-                                         int& n_stamp) {
-  constexpr int T2 = NT - T1;
-  constexpr int T1A = T1 > 0 ? T1 : 1, T2A = T2 > 0 ? T2 : 1;   // array extents (a role may have no P1 or no P2 tile: NT = 1)
-  const int w4 = wave & 3, l15 = lane & 15, kq = lane >> 4;
+                                         int P1F, int P2F, int& n_stamp) {
+  constexpr int T1A = T1 > 0 ? T1 : 1, T2A = T2 > 0 ? T2 : 1;   // array extents (a role may have no P1 or no P2 tile)
+  const int l15 = lane & 15, kq = lane >> 4;
   const int np = p.I / 32;
   // LDS-DMA of one image by all 8 waves: wave w copies KiB blocks w, w+8, ... (64 lanes x 16 B, lane-linear on both
   // sides); asm with a SCALAR base + one per-lane byte offset: no 64-bit per-lane pointers live across the panel loop
@@ -177,7 +177,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     MLP_GLDS_2(src__, dst__);                                                                                      \
   } while (0)
 
-  const int tok0 = tile * (64 * NT) + w4 * (16 * NT) + l15;   // token of tile j: tok0 + 16 j
+  const int tok0 = tile * (16 * TPB) + l15;   // token of block tile g: tok0 + 16 g
   // explicitly global (address space 1) byte pointers: accesses are then global_* with an SGPR base, never flat_*
   typedef __attribute__((address_space(1))) char gchar;
   typedef __attribute__((address_space(1))) const char gcchar;
@@ -366,7 +366,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
         // ---- P2 MFMAs of panel it-1: y^T += W3slice h^T ----
         const int pn = it - 1;
         const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
-        const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT + P2F) * 64 + lane;
+        const uint4* hsrc = hb + ((pn & 1) * TPB + P2F) * 64 + lane;
         bf16x8 hf[T2A];
   #pragma unroll
         for (int j = 0; j < T2; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
@@ -386,7 +386,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     }
     if (T1 > 0 && it < np) {
       // ---- GEGLU of panel `it` in registers -> one B fragment of the second product per token tile ----
-      uint4* hdst = hb + (((it & 1) * 4 + w4) * NT + P1F) * 64 + lane;
+      uint4* hdst = hb + ((it & 1) * TPB + P1F) * 64 + lane;
 #pragma unroll
       for (int j = 0; j < T1; ++j) {
         float gg[8], xx[8], hh[8];
@@ -413,7 +413,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
         // ---- P2 MFMAs of panel it-1: y^T += W3slice h^T ----
         const int pn = it - 1;
         const uint4* w3l = l3 + (pn & 1) * MLP_W3_CHUNKS + kq * 256 + l15;
-        const uint4* hsrc = hb + (((pn & 1) * 4 + w4) * NT + P2F) * 64 + lane;
+        const uint4* hsrc = hb + ((pn & 1) * TPB + P2F) * 64 + lane;
         bf16x8 hf[T2A];
   #pragma unroll
         for (int j = 0; j < T2; ++j) hf[j] = __builtin_bit_cast(bf16x8, hsrc[j * 64]);
@@ -442,12 +442,12 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
   // the 96 KiB they occupied hold exactly the 4 x NT token tiles of the block at 8 KiB each; a lane of the P2 wave needs, for the
   // m-tiles 2 s8 and 2 s8 + 1, the very 8 values the same lane of the P1 wave holds in bfr[.][s8] (the C layout of the second
   // product IS the B-fragment layout of the first): one 16-byte vector per (tile, s8), lane to same lane, no conflicts. ----
-  uint4* const xres = l12;      // [4 wave pairs][NT][8][64 lanes]; l3 follows l12 in the block's LDS
+  uint4* const xres = l12;      // [TPB tiles][8][64 lanes] (<= 96 KiB: 12 tiles); l3 follows l12 in the block's LDS
   if (FRONT) {
 #pragma unroll
     for (int j = 0; j < T1; ++j)
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) xres[((w4 * NT + P1F + j) * 8 + s8) * 64 + lane] = __builtin_bit_cast(uint4, bfr[j][s8]);
+      for (int s8 = 0; s8 < 8; ++s8) xres[((P1F + j) * 8 + s8) * 64 + lane] = __builtin_bit_cast(uint4, bfr[j][s8]);
     __syncthreads();
   }
 
@@ -466,7 +466,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     for (int s8 = 0; s8 < 8; ++s8) {
       f32x4 rv0, rv1;
       if (FRONT) {
-        const bf16x8 rb = __builtin_bit_cast(bf16x8, xres[((w4 * NT + P2F + j) * 8 + s8) * 64 + lane]);
+        const bf16x8 rb = __builtin_bit_cast(bf16x8, xres[((P2F + j) * 8 + s8) * 64 + lane]);
         rv0 = (f32x4){(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
         rv1 = (f32x4){(float)rb[4], (float)rb[5], (float)rb[6], (float)rb[7]};
       } else {
@@ -622,27 +622,41 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
 #undef GLDS_W3
 }
 
-template <int NT, bool KEEL, bool FRONT, bool BACK>
+// TILES = 16-token tiles per block.  4 NT (NT = 1, 2, 3): the pair layout described above.  9 (144 tokens): the benchmark batch
+// (36 864 tokens) is then 256 blocks - one per CU instead of 192 - and the nine tiles are dealt over the eight waves so that the
+// longest wave is shorter than in the pair layout (lone-wave cost of a P1 tile ~ 3.5 P2 tiles: 32 MFMAs + the GEGLU against 16 MFMAs):
+//     wave 0..3: P1 of tiles {2w, 2w+1}      wave 4: P2 of {0,1,2}   wave 5: P2 of {3,4,5}   wave 6: P1 of {8} + P2 of {6}   wave 7: P2 of {7,8}
+// (SIMD s runs waves s and s+4).  Four role programs instead of two.
+template <int TILES, bool KEEL, bool FRONT, bool BACK>
 __global__ __launch_bounds__(512, 1) void k_mlp256(MlpDev p) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* const l12 = smem;                                 // [2][MLP_W12_CHUNKS]
   uint4* const l3 = smem + 2 * MLP_W12_CHUNKS;             // [2][MLP_W3_CHUNKS]
-  uint4* const hb = l3 + 2 * MLP_W3_CHUNKS;                // [2][4 wave pairs][NT][64 lanes]
-  float* const gl = reinterpret_cast<float*>(hb + 2 * 4 * NT * 64);   // [256] post_gain, [256] front_gain (read per m-tile by
-                                                                       // low-latency LDS loads instead of serialised global loads)
+  uint4* const hb = l3 + 2 * MLP_W3_CHUNKS;                // [2][TILES][64 lanes]
+  float* const gl = reinterpret_cast<float*>(hb + 2 * TILES * 64);   // [256] post_gain, [256] front_gain (read per m-tile by
+                                                                      // low-latency LDS loads instead of serialised global loads)
   if (threadIdx.x < 256) {
     gl[threadIdx.x] = p.post_gain ? p.post_gain[threadIdx.x] : 1.0f;
     gl[256 + threadIdx.x] = (FRONT && p.front_gain) ? p.front_gain[threadIdx.x] : 1.0f;
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: DMA bases / role branch stay in SGPRs
-  constexpr int TA = NT - NT / 2;   // P1 tiles of the first wave of a pair (2 of 3, 1 of 2)
   int n_stamp = 0;
   // one tile per block (grid = n_tiles; with more tiles than CUs the dispatcher queues the rest - one block fits a CU): inside a
   // persistent tile loop the compiler hoisted lane constants of every phase to the top and spilled them around the 256-VGPR body
   const int tile = blockIdx.x;
-  if (wave < 4) mlp_wave<NT, TA, 0, TA, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
-  else mlp_wave<NT, NT - TA, TA, 0, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, n_stamp);
+  if constexpr (TILES == 9) {
+    if (wave < 4) mlp_wave<9, 2, 0, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, 2 * wave, 0, n_stamp);
+    else if (wave < 6) mlp_wave<9, 0, 3, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, 0, 3 * (wave - 4), n_stamp);
+    else if (wave == 6) mlp_wave<9, 1, 1, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, 8, 6, n_stamp);
+    else mlp_wave<9, 0, 2, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, 0, 7, n_stamp);
+  } else {
+    constexpr int NT = TILES / 4;
+    constexpr int TA = NT - NT / 2;   // P1 tiles of the first wave of a pair (2 of 3, 1 of 2)
+    const int g0 = (wave & 3) * NT;   // first tile of the wave pair
+    if (wave < 4) mlp_wave<TILES, TA, NT - TA, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, g0, g0 + TA, n_stamp);
+    else mlp_wave<TILES, NT - TA, TA, false, KEEL, FRONT, BACK>(p, l12, l3, hb, gl, tile, wave, lane, g0 + TA, g0, n_stamp);
+  }
 }
 #undef MLP_LD12
 #undef MLP_GLDS_4
@@ -689,37 +703,53 @@ int ttvk_mlp_fused(const void* ao, int ldao, const float* front_gain, float fron
     d.qkv = (bf16_t*)nq->qkv; d.ldq = nq->ld; d.rope_cs = nq->rope_cs; d.nqp = nq->rows / 64;
     d.rope_q_end = nq->rope_q_end; d.rope_k_begin = nq->rope_k_begin; d.rope_k_end = nq->rope_k_end;
   }
-  // tokens per wave pair (NT*16): tile size with the smallest (rounds over the 256 CUs) x (cost of one tile); a tile costs
-  // about 16 + 19*NT us (measured: 54 us at NT = 2, 73 us at NT = 3), so small batches - the reference trains under a
-  // 6144-token budget, configs/tiny.yaml:65 - take 64-token tiles on many CUs rather than a few CUs with fat tiles
+  // 16-token tiles per block: 4, 8, 12 (wave pairs with 1, 2, 3 tiles each) or 9 (the eight-wave deal of k_mlp256).  The choice
+  // minimises (rounds over the 256 CUs) x (cost of one block): a block costs about 16 + 19 NT us in the pair layout (measured: 54 us at
+  // NT = 2, 62 us at NT = 3) - small batches (the reference trains under a 6144-token budget, configs/tiny.yaml:65) take 64-token
+  // blocks on many CUs rather than a few CUs with fat blocks - and 9-tile blocks cost less than 12-tile ones and fill all 256 CUs at
+  // the benchmark batch (36 864 tokens = 256 x 144).  The fused next-QKV phase exists for the pair layouts only.
   const int cus = 256;
-  int nt = 1;
+  int tiles = 4;
   long best = -1;
   for (int c = 1; c <= 3; ++c) {
     const long cost = (long)ttv_cdiv(ttv_cdiv(M, 64 * c), cus) * (16 + 19 * c);
-    if (best < 0 || cost < best) { best = cost; nt = c; }
+    if (best < 0 || cost < best) { best = cost; tiles = 4 * c; }
   }
-  if (g_ttv_debug & 8) nt = 2;     // debug bit3 forces the 2-tile variant
-  if (g_ttv_debug & 64) nt = 1;    // debug bit6 forces the 1-tile variant
-  d.n_tiles = ttv_cdiv(M, 64 * nt);
+  if (!nq && !(g_ttv_debug & 32)) {      // debug bit5: pair layouts only (A/B)
+    const long cost9 = (long)ttv_cdiv(ttv_cdiv(M, 144), cus) * (16 + 14 * 3);
+    if (cost9 < best) { best = cost9; tiles = 9; }
+  }
+  if ((g_ttv_debug & 512) && !nq) tiles = 9;   // debug bit9 forces the 9-tile deal (tests)
+  if (g_ttv_debug & 8) tiles = 8;      // debug bit3 forces the 2-tile pair variant
+  if (g_ttv_debug & 64) tiles = 4;     // debug bit6 forces the 1-tile pair variant
+  d.n_tiles = ttv_cdiv(M, 16 * tiles);
   const int grid = d.n_tiles;
-  const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * 4 * nt * 64) * sizeof(uint4) + 2048;   // 96 KiB + 8 KiB per token tile + gains
+  const size_t smem = (size_t)(2 * MLP_W12_CHUNKS + 2 * MLP_W3_CHUNKS + 2 * tiles * 64) * sizeof(uint4) + 2048;   // 96 KiB + 2 KiB per token tile + gains
   TtvProfScope prof(TTV_KC_GEMM_GEGLU, s);
-#define LAUNCH_MLP(NT_, KEEL_, FRONT_, BACK_)                                                                       \
+#define LAUNCH_MLP(TILES_, KEEL_, FRONT_, BACK_)                                                                    \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)k_mlp256<NT_, KEEL_, FRONT_, BACK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((k_mlp256<NT_, KEEL_, FRONT_, BACK_>), dim3(grid), dim3(512), smem, s, d);                   \
+    (void)hipFuncSetAttribute((const void*)k_mlp256<TILES_, KEEL_, FRONT_, BACK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((k_mlp256<TILES_, KEEL_, FRONT_, BACK_>), dim3(grid), dim3(512), smem, s, d);                \
   } while (0)
   // the fused back exists only together with the fused front (the layer-tail use): keeps the instantiation count down
-#define LAUNCH_MLP_F(NT_, KEEL_)                                                                                    \
+#define LAUNCH_MLP_F(TILES_, KEEL_)                                                                                 \
   do {                                                                                                              \
-    if (ao && nq) LAUNCH_MLP(NT_, KEEL_, true, true);                                                               \
-    else if (ao) LAUNCH_MLP(NT_, KEEL_, true, false);                                                               \
-    else LAUNCH_MLP(NT_, KEEL_, false, false);                                                                      \
+    if (ao && nq) LAUNCH_MLP(TILES_, KEEL_, true, true);                                                            \
+    else if (ao) LAUNCH_MLP(TILES_, KEEL_, true, false);                                                            \
+    else LAUNCH_MLP(TILES_, KEEL_, false, false);                                                                   \
+  } while (0)
+#define LAUNCH_MLP_9(KEEL_)                                                                                         \
+  do {                                                                                                              \
+    if (ao) LAUNCH_MLP(9, KEEL_, true, false);                                                                      \
+    else LAUNCH_MLP(9, KEEL_, false, false);                                                                        \
   } while (0)
   TTV_CHECK_ARG(!nq || ao, "mlp_fused: the next-qkv part needs the out_proj front (ttv_layer_tail_fused)");
-  if (post_gain) { if (nt == 3) LAUNCH_MLP_F(3, true); else if (nt == 2) LAUNCH_MLP_F(2, true); else LAUNCH_MLP_F(1, true); }
-  else { if (nt == 3) LAUNCH_MLP_F(3, false); else if (nt == 2) LAUNCH_MLP_F(2, false); else LAUNCH_MLP_F(1, false); }
+  if (post_gain) {
+    if (tiles == 9) LAUNCH_MLP_9(true); else if (tiles == 12) LAUNCH_MLP_F(12, true); else if (tiles == 8) LAUNCH_MLP_F(8, true); else LAUNCH_MLP_F(4, true);
+  } else {
+    if (tiles == 9) LAUNCH_MLP_9(false); else if (tiles == 12) LAUNCH_MLP_F(12, false); else if (tiles == 8) LAUNCH_MLP_F(8, false); else LAUNCH_MLP_F(4, false);
+  }
+#undef LAUNCH_MLP_9
 #undef LAUNCH_MLP_F
 #undef LAUNCH_MLP
   TTV_CHECK_LAUNCH("mlp_fused");
