@@ -149,3 +149,62 @@ def test_overlapped_gradient_reduction_equals_the_sequential_one_bit_for_bit():
     # and both ranks hold the same reduced gradients
     for n in res[0][1][True]:
         assert np.array_equal(res[0][1][True][n], res[1][1][True][n]), n       # an all-reduce leaves the same bits on every rank
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" is RCCL on ROCm
+    try:
+        from titok_video_amd import dp
+        from titok_video_amd.model.titok import TiTok
+        from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
+        from titok_video_amd.train import make_optimizer, training_step
+        cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(
+            patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5], encoder_size="tiny", decoder_size="tiny")))
+        out = {}
+        for overlap in (True, False):
+            model = TiTok(cfg)
+            model.load_state_dict(seeded_titok_state(0), strict=True)
+            model = model.to(dev, torch.float32).train()
+            all_clips = synthetic_clips(SHAPES, seed=77, dtype=torch.float32, device=dev)
+            mine = dp.shard_clips(len(SHAPES), rank, world)
+            opt = make_optimizer(model)
+            loss, gnorm, idx = training_step(model, [all_clips[i] for i in mine], [COUNTS[i] for i in mine], opt, overlap=overlap)
+            torch.cuda.synchronize(dev)
+            out[overlap] = ({n: p.detach().cpu().numpy() for n, p in model.named_parameters()}, float(gnorm))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than two")
+def test_two_rank_training_step_over_rccl_equals_single_process():
+    """The same union-batch equality as above with one GPU per rank and backend "nccl" (RCCL over xGMI), overlapped and sequential
+    reduction.  Skipped on one-GPU boxes (every box this code was developed on): it exists for the first multi-GPU lease."""
+    from titok_video_amd.synthetic import synthetic_clips
+    from titok_video_amd.train import make_optimizer, training_step
+    model = _model()
+    clips = synthetic_clips(SHAPES, seed=77, dtype=torch.float32, device="cuda:0")
+    opt = make_optimizer(model)
+    loss, gnorm, idx = training_step(model, clips, COUNTS, opt)
+    ref = {n: p.detach().cpu() for n, p in model.named_parameters()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for overlap, (params, gn) in out.items():
+            assert abs(gn - float(gnorm)) < 1e-3 * float(gnorm), (rank, overlap)
+            for n, v in params.items():
+                err = float((torch.from_numpy(v) - ref[n]).norm() / (ref[n].norm() + 1e-30))
+                assert err < 1e-5, (rank, overlap, n, err)
