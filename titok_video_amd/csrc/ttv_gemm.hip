@@ -1251,7 +1251,16 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     const int fo = (EPI == EPI_GEGLU) ? 32 : 64;
     const int n_panels = ttv_cdiv(d.N, fo), n_tiles = ttv_cdiv(d.M, K256_TT);
     const int total = n_panels * n_tiles;
-    const int grid = total < 512 ? total : 512;   // 2 co-resident blocks per CU
+    // 2 co-resident blocks per CU = 512 slots.  Blocks take contiguous item ranges; with a grid that does not divide the item count
+    // some blocks get one item more and set the launch time (QKV at the benchmark batch: 3456 items on 512 blocks = 6 or 7 each,
+    // on 432 blocks 8 each: 34.6 -> 33.6 us), so the largest divisor of the item count in [384, 512] is preferred.
+    // TTV_K256_GRID overrides (A/B).
+    static const int grid_env = getenv("TTV_K256_GRID") ? atoi(getenv("TTV_K256_GRID")) : 0;
+    int grid = total < 512 ? total : 512;
+    if (grid_env > 0) grid = total < grid_env ? total : grid_env;
+    else if (total > 512)
+      for (int g = 512; g >= 384; g -= 8)      // multiples of 8: the XCD remap deals blocks over 8 lists
+        if (total % g == 0) { grid = g; break; }
     if (prenorm) hipLaunchKernelGGL((k_gemm_k256<EPI, true>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
     else hipLaunchKernelGGL((k_gemm_k256<EPI, false>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
     TTV_CHECK_LAUNCH("gemm_k256");
