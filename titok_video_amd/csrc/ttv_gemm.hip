@@ -1251,15 +1251,18 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     const int fo = (EPI == EPI_GEGLU) ? 32 : 64;
     const int n_panels = ttv_cdiv(d.N, fo), n_tiles = ttv_cdiv(d.M, K256_TT);
     const int total = n_panels * n_tiles;
-    // 2 co-resident blocks per CU = 512 slots.  Blocks take contiguous item ranges; with a grid that does not divide the item count
-    // some blocks get one item more and set the launch time (QKV at the benchmark batch: 3456 items on 512 blocks = 6 or 7 each,
-    // on 432 blocks 8 each: 34.6 -> 33.6 us), so the largest divisor of the item count in [384, 512] is preferred.
-    // TTV_K256_GRID overrides (A/B).
+    // 2 co-resident blocks per CU = 512 slots.  Blocks take contiguous (tile, panel) item ranges and reload their token rows
+    // whenever a range crosses into the next tile (-5 us of 34.6 with that reload knocked out).  With an item count per block that
+    // is an integer, the ranges repeat with a short period against the panels of a tile and fewer of them straddle: QKV at the
+    // benchmark batch, 3456 items = 288 tiles x 12 panels: 512 blocks x 6.75 items - more than half of the blocks straddle -
+    // 34.6 us; 432 blocks x 8 items - one in three - 33.6 us (576 x 6, aligned but more than 512 slots: 35.2; 384 x 9: 37.4).
+    // So: the largest grid in [416, 512] that divides the item count, else 512 (a grid much below the slot count loses more
+    // than it gains: GEGLU, 6336 items, 396 x 16: 46 us against 41).  TTV_K256_GRID overrides (A/B).
     static const int grid_env = getenv("TTV_K256_GRID") ? atoi(getenv("TTV_K256_GRID")) : 0;
     int grid = total < 512 ? total : 512;
     if (grid_env > 0) grid = total < grid_env ? total : grid_env;
     else if (total > 512)
-      for (int g = 512; g >= 384; g -= 8)      // multiples of 8: the XCD remap deals blocks over 8 lists
+      for (int g = 512; g >= 416; --g)
         if (total % g == 0) { grid = g; break; }
     if (prenorm) hipLaunchKernelGGL((k_gemm_k256<EPI, true>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
     else hipLaunchKernelGGL((k_gemm_k256<EPI, false>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
