@@ -178,6 +178,13 @@ int ttv_decoder_embed(const void* codes, int token_size, const void* w, const vo
                                 slower than the plain loop, see ttv_attn.hip; the towers set it under the environment switch TTV_ATTN_PIPE=1) */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
+/* The same operator (transformer.py:100,103) on the 64-query-rows-per-wave kernel: bf16, head_dim 64, q pre-scaled (flags must carry
+ * TTV_ATTN_QSCALED; TTV_ATTN_GATE as above).  One workgroup = 4 waves, one per SIMD, each with 64 query rows (two 32-row tiles that
+ * share every K / V fragment read) of any q-head of ONE (sequence, kv-head).  items: device int32 [n_items, 8] =
+ * (sequence id, kv-head, wave 0..3: q-head | (first query row / 64) << 8, or -1 for an idle wave, 0, 0); sequence id -1 = padding.
+ * The host orders the table so that entries i, i+8, ... (one XCD under round-robin dispatch) share a (sequence, kv-head). */
+int ttv_attention64(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* items, int n_items,
+                    int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 
 /* patch_rearrange (model/base/utils.py:26-34) for up to TTV_MAX_CLIPS_PER_LAUNCH clips per call.
  * clips: HOST array of device pointers [n_clips] to [C,T,H,W] tensors; clip_desc: DEVICE int32 [n_clips,8] =
@@ -272,6 +279,10 @@ typedef struct ttv_batch {
   int32_t qblocks_paired;      /* 1: entries 2j, 2j+1 of every XCD list of `qblocks` are the same query rows of two q-heads sharing
                                   a kv-head (ttv_attention flag TTV_ATTN_PAIRED); 0: no such guarantee */
   int32_t qblocks_all_full;    /* 1: `qblocks` holds full items only (ttv_attention flag TTV_ATTN_ALLFULL) */
+  /* optional: the work table of ttv_attention64 for this tower's head counts (NULL / 0: the towers use `qblocks` only).  When given,
+   * inference forwards of bf16 towers whose q columns are pre-scaled run ttv_attention64 instead of ttv_attention. */
+  const int32_t* items64;
+  int32_t n_items64;
 } ttv_batch;
 
 /* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =

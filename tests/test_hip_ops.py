@@ -435,6 +435,66 @@ def test_attention_online_softmax_rescale_branch(split, qscaled, spike):
     assert_close(out.float(), ref, "bf16", scale=2.0)
 
 
+@pytest.mark.parametrize("case", [([(4, 16, 16)], [1]), ([(8, 32, 48), (4, 8, 24), (16, 64, 64)], [5, 3, 128]),
+                                  ([(16, 128, 128)], [128]), ([(4, 8, 8), (4, 8, 8)], [0, 63]), ([(16, 64, 64)] * 3, [0, 61, 128])])
+@pytest.mark.parametrize("heads", [(4, 2), (12, 4), (2, 2)])
+def test_attention64_varlen_gqa_gate(case, heads):
+    """ttv_attention64 (64 query rows per wave, one wave per SIMD) against the oracle's per-sequence softmax attention
+    (reference transformer.py:100,103): ragged sequences (lengths 5 .. 1152, not multiples of 64: clamped rows, masked keys, idle
+    waves), GQA groups of 1, 2 and 3 q-heads, with and without the gate."""
+    shapes, counts = case
+    plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
+    hq, hkv = heads
+    d, gq = hq * 64, hkv * 64
+    ld = 2 * d + 2 * gq
+    g = torch.Generator().manual_seed(len(shapes) + hq)
+    qkvg = torch.randn(plan.total_rows, ld, generator=g)
+    qkvg[:, :d] *= 2.0
+    q_f32 = qkvg[:, :d].clone()
+    qkvg = qkvg.to(torch.bfloat16)
+    out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
+    xd = qkvg.to(DEV)
+    xd[:, :d] = (q_f32 * (0.125 * 1.4426950408889634)).to(torch.bfloat16).to(DEV)   # TTV_ATTN_QSCALED
+    tab = plan.attention_table64(hq, hkv)
+    f = qkvg.float()
+    q, gt, k, v = f.split([d, d, gq, gq], dim=-1)
+    ref0 = O.attention_varlen(q.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)
+    for gate in (1, 0):
+        out.fill_(float("nan"))
+        _lib.check(L().ttv_attention64(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(), tab.shape[0], hq, hkv, 64,
+                                       gate | 4, _lib.TTV_BF16, S()), "attention64")
+        ref = ref0 * torch.sigmoid(gt) if gate else ref0
+        assert_close(out.float(), ref, "bf16", scale=2.0)
+
+
+@pytest.mark.parametrize("spike", [6.0, 30.0])
+@pytest.mark.parametrize("spike_key", [200, 20, 264])
+def test_attention64_reference_shift_branch(spike, spike_key):
+    """Force the softmax reference of ttv_attention64 to move at a chosen key tile (one key spiked against one query direction): the
+    wave-uniform shift of scores, row sum, O (accumulation registers) and the -m start vector, for tile A and tile B rows, in the
+    first tile, a middle tile and the masked last tile."""
+    plan = BatchPlan([(16, 64, 64)], [9], (4, 8, 8), DEV)  # S = 265 -> 5 key tiles, the last with 9 keys
+    hq, hkv, d, gq = 4, 2, 256, 128
+    ld = 2 * d + 2 * gq
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(plan.total_rows, ld, generator=g) * 0.5
+    q = x[:, :d].view(-1, 4, 64)
+    x[spike_key, 2 * d: 2 * d + gq] = spike * torch.sign(q[5, 0]).repeat(2)   # dominates for query 5 (tile A) and its neighbours
+    x[40, :64] = q[5, 0]                                                      # the same direction in a tile-B row (row 40 of its wave)
+    q_f32 = x[:, :d].clone()
+    x = x.to(torch.bfloat16)
+    out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
+    xd = x.to(DEV)
+    xd[:, :d] = (q_f32 * (0.125 * 1.4426950408889634)).to(torch.bfloat16).to(DEV)
+    tab = plan.attention_table64(hq, hkv)
+    _lib.check(L().ttv_attention64(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(), tab.shape[0], hq, hkv, 64, 4,
+                                   _lib.TTV_BF16, S()), "attention64")
+    f = x.float()
+    qq, gt, k, v = f.split([d, d, gq, gq], dim=-1)
+    ref = O.attention_varlen(qq.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)
+    assert_close(out.float(), ref, "bf16", scale=2.0)
+
+
 # ---------------------------------------------------------------------------------------------- patches
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_patch_gather_scatter(dt):

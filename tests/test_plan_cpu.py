@@ -143,3 +143,30 @@ def test_forward_pipeline_needs_a_gpu_model():
         ForwardPipeline(TiTok(cfg), depth=2)
     with pytest.raises(ValueError):
         ForwardPipeline(TiTok(cfg), depth=0)
+
+
+def test_attention_table64_covers_every_row_slice_once():
+    """Work table of ttv_attention64: every (sequence, q-head, 64-row slice) appears in exactly one wave slot, all four waves of a
+    workgroup share the (sequence, kv-head), and the entries i, i + 8, ... of one list keep a unit together."""
+    from titok_video_amd.plan import BatchPlan
+    plan = BatchPlan([(8, 32, 48), (4, 8, 24), (16, 128, 128), (4, 16, 16)], [5, 3, 128, 1], (4, 8, 8), "cpu")
+    for hq, hkv in ((4, 2), (12, 4), (2, 2)):
+        t = plan.attention_table64(hq, hkv).numpy()
+        rep = hq // hkv
+        seen = set()
+        for e in t:
+            if e[0] < 0:
+                continue
+            s = plan.cu_seqlens[e[0] + 1] - plan.cu_seqlens[e[0]]
+            for w in e[2:6]:
+                if w < 0:
+                    continue
+                head, q64 = int(w) & 0xff, int(w) >> 8
+                assert head // rep == e[1] and q64 * 64 < s
+                assert (int(e[0]), head, q64) not in seen
+                seen.add((int(e[0]), head, q64))
+        want = {(b, h, q) for b in range(4) for h in range(hq) for q in range(-(-(plan.cu_seqlens[b + 1] - plan.cu_seqlens[b]) // 64))}
+        assert seen == want
+    # the benchmark batch: 32 x 1152 rows, 4/2 heads -> 576 workgroups, no idle wave
+    big = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu").attention_table64(4, 2).numpy()
+    assert big.shape[0] == 576 and (big[:, 2:6] >= 0).all()

@@ -54,7 +54,7 @@ class Batch(C.Structure):
     _fields_ = [("n_clips", i32), ("total_rows", i32), ("sum_tokens", i32), ("sum_patches", i32),
                 ("max_patches_per_clip", i32), ("n_qblocks", i32), ("cu_seqlens", vp), ("latent_rows", vp),
                 ("patch_rows", vp), ("clip_desc", vp), ("qblocks", vp), ("rope_cs", vp), ("blocks64", vp), ("row_seq", vp),
-                ("n_blocks64", i32), ("qblocks_paired", i32), ("qblocks_all_full", i32)]
+                ("n_blocks64", i32), ("qblocks_paired", i32), ("qblocks_all_full", i32), ("items64", vp), ("n_items64", i32)]
 
 
 class LayerWeightsT(C.Structure):
@@ -107,6 +107,7 @@ SYMBOLS = {
     "ttv_fill_const_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, f32, vp]),
     "ttv_decoder_embed": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, f32, vp]),
     "ttv_attention": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_attention64": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_patch_gather": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int,
                                    C.c_int, C.c_int, vp]),
     "ttv_patch_scatter": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp),

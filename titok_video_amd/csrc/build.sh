@@ -6,12 +6,12 @@ OUT=../libtitok_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vectorize -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
-for f in ttv_elem ttv_gemm ttv_attn ttv_mlp ttv_bwd ttv_train ttv_vq ttv_api; do
+for f in ttv_elem ttv_gemm ttv_attn ttv_attn64 ttv_mlp ttv_bwd ttv_train ttv_vq ttv_api; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ ttv_common.h -nt build/$f.o ] || [ ttv_kernels.h -nt build/$f.o ] || [ ../../include/titok_hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o build/ttv_gemm.o build/ttv_attn.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o build/ttv_gemm.o build/ttv_attn.o build/ttv_attn64.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o $OUT
 echo "built $(realpath $OUT)"

@@ -116,6 +116,10 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     // q arrives pre-scaled when the projection used the folded weight whose q rows carry scale * log2(e)
     const bool q_scaled = dt == TTV_BF16 && ((dm == 256 && lw.to_qkv_pn) ? lw.qkv_q_prescaled != 0 : lw.to_qkv_qs != nullptr);
     qkv_ready = false;
+    if (q_scaled && b->items64 && b->n_items64 > 0 && d->head_dim == 64)
+      TTV_TRY(ttvk_attention64(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->items64, b->n_items64, d->q_heads, d->kv_heads,
+                               TTV_ATTN_GATE | TTV_ATTN_QSCALED, s));
+    else
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
                                (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
@@ -350,6 +354,11 @@ int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* c
                   int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream) {
   TTV_CHECK_ARG(n_qblocks == 0 || (qkvg && out && cu_seqlens && qblocks), "attention: null buffer");
   return ttvk_attention(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, head_dim, flags, dtype, (hipStream_t)stream);
+}
+int ttv_attention64(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* items, int n_items, int q_heads,
+                    int kv_heads, int head_dim, int flags, int dtype, void* stream) {
+  TTV_CHECK_ARG(dtype == TTV_BF16 && head_dim == 64, "attention64: bf16, head_dim 64 only");
+  return ttvk_attention64(qkvg, ld, out, ldo, cu_seqlens, items, n_items, q_heads, kv_heads, flags, (hipStream_t)stream);
 }
 
 int ttv_patch_gather(const void* const* clips, const int32_t* clip_desc, int clip0, int n_clips, int patch_t, int patch_h, int patch_w,

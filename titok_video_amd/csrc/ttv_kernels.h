@@ -75,6 +75,10 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
                    int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out = nullptr,
                    void* out_raw = nullptr);
 
+// ---- ttv_attn64.hip ----
+int ttvk_attention64(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* items, int n_items, int q_heads,
+                     int kv_heads, int flags, hipStream_t s);
+
 // ---- ttv_vq.hip (nearest-codebook-entry quantiser) ----
 int ttvk_vq_norms(const void* cb, int dtype, int ld, int N, int C, float* cnorm, hipStream_t s);
 int64_t ttvk_vq_workspace_bytes(int rows);

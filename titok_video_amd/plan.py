@@ -254,6 +254,44 @@ class BatchPlan:
             self._attn_all_full[t.data_ptr()] = not bool((flat[:last, 3] > 0).any())
         return t
 
+    def attention_table64(self, q_heads: int, kv_heads: int) -> torch.Tensor:
+        """int32 [n,8] work table of ttv_attention64 (the 64-query-rows-per-wave kernel): one entry per workgroup =
+        (sequence, kv-head, 4 x wave item, 0, 0); a wave item is q-head | (first query row // 64) << 8, or -1 for an idle wave.
+
+        All wave items of one (sequence, kv-head) unit - every 64-row slice of every q-head of the group - read the same K / V, so a
+        unit's items are dealt four at a time to workgroups (the four waves of a workgroup share each K / V tile through LDS) and the
+        unit's workgroups go to one of 8 lists (greedy by count); entry i of the flat table belongs to list i % 8 (blocks b, b + 8
+        share an XCD under round-robin dispatch: L2 affinity only, never correctness).  Shorter lists are padded with sequence -1."""
+        key = ("w64", int(q_heads), int(kv_heads))
+        t = self._attn.get(key)
+        if t is None:
+            rep = q_heads // kv_heads
+            units = []
+            for b in range(len(self.grids)):
+                s = self.cu_seqlens[b + 1] - self.cu_seqlens[b]
+                n64 = -(-s // 64)
+                for kvh in range(kv_heads):
+                    items = [(kvh * rep + r) | (q << 8) for q in range(n64) for r in range(rep)]
+                    items += [-1] * (-len(items) % 4)
+                    units.append([(b, kvh, *items[i:i + 4], 0, 0) for i in range(0, len(items), 4)])
+            order = sorted(range(len(units)), key=lambda i: len(units[i]), reverse=True)
+            lists, weight = [[] for _ in range(8)], [0] * 8
+            for i in order:
+                x = min(range(8), key=lambda j: weight[j])
+                lists[x].extend(units[i])
+                weight[x] += len(units[i])
+            depth = max(len(l) for l in lists)
+            table = np.zeros((depth, 8, 8), dtype=np.int32)
+            table[:, :, 0] = -1
+            for x, l in enumerate(lists):
+                if l:
+                    table[: len(l), x, :] = np.asarray(l, dtype=np.int32)
+            flat = table.reshape(-1, 8)
+            last = int(np.max(np.nonzero(flat[:, 0] >= 0)[0])) + 1
+            t = _upload(np.ascontiguousarray(flat[:last]), self.device)
+            self._attn[key] = t
+        return t
+
     def batch_for(self, q_heads: int, kv_heads: int) -> "_lib.Batch":
         """ttv_batch struct whose attention work table matches the tower's head counts."""
         t = self.attention_table(q_heads, kv_heads)
@@ -263,7 +301,12 @@ class BatchPlan:
         # the grid coarser: the launch alone is 10 % slower)
         paired = 1 if (q_heads // kv_heads) % 2 == 0 and os.environ.get("TTV_ATTN_PAIRED", "0") == "1" else 0
         all_full = 1 if self._attn_all_full.get(t.data_ptr()) else 0
-        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full, **self._base_fields)
+        # the 64-rows-per-wave kernel (one wave per SIMD) for inference towers with pre-scaled q; TTV_ATTN64=0 keeps the
+        # 32-rows-per-wave kernel everywhere (A/B measurements)
+        t64 = self.attention_table64(q_heads, kv_heads) if (q_heads <= 255 and os.environ.get("TTV_ATTN64", "1") != "0") else None
+        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
+                          items64=t64.data_ptr() if t64 is not None else None, n_items64=int(t64.shape[0]) if t64 is not None else 0,
+                          **self._base_fields)
 
     # views used by tests that call single ops
     def table(self, i: int, n: int) -> torch.Tensor:

@@ -23,6 +23,8 @@ L, S = plan.total_rows, plan.total_rows // B
 dm, g = HQ * D, HKV * D
 ld = 2 * dm + 2 * g
 table = plan.attention_table(HQ, HKV)
+table64 = plan.attention_table64(HQ, HKV)
+W64 = 1 << 20          # tool-local marker: run ttv_attention64 (the 64-rows-per-wave kernel)
 C_EXP = 0.125 * 1.4426950408889634
 
 
@@ -46,6 +48,10 @@ def run(dtype, flags, qkv, iters=30):
     code = _lib.dtype_code(dtype)
 
     def call():
+        if flags & W64:
+            _lib.check(lib.ttv_attention64(qkv.data_ptr(), ld, out.data_ptr(), dm, plan.cu_dev.data_ptr(), table64.data_ptr(),
+                                           table64.shape[0], HQ, HKV, D, flags & ~W64, code, ST), "attention64")
+            return
         _lib.check(lib.ttv_attention(qkv.data_ptr(), ld, out.data_ptr(), dm, plan.cu_dev.data_ptr(), table.data_ptr(), table.shape[0],
                                      HQ, HKV, D, flags, code, ST), "attention")
     for _ in range(3):
@@ -62,7 +68,7 @@ def run(dtype, flags, qkv, iters=30):
 
 spreads = [float(a) for a in sys.argv[1:]] or [1.5, 6.0]
 flops = B * 4.0 * S * S * dm
-print(f"shape: {B} x {S} rows, {HQ}/{HKV} heads, table {table.shape[0]} entries, {flops / 1e9:.1f} GFLOP per launch")
+print(f"shape: {B} x {S} rows, {HQ}/{HKV} heads, table {table.shape[0]} entries (w64: {table64.shape[0]} workgroups), {flops / 1e9:.1f} GFLOP per launch")
 for spread in spreads:
     gen = torch.Generator(device="cpu").manual_seed(7)
     base = torch.randn(L, ld, generator=gen)
@@ -72,6 +78,7 @@ for spread in spreads:
     base[:, 2 * dm:2 * dm + g] *= a
     all_full = 8 if not bool((table[:, 3] > 0).any()) else 0
     variants = [(torch.bfloat16, "bf16 gate", 1, False), (torch.bfloat16, "bf16 gate+qscaled", 1 | 4, True)]
+    variants.append((torch.bfloat16, "bf16 gate+qscaled w64", 1 | 4 | W64, True))
     if all_full:
         variants.append((torch.bfloat16, "bf16 gate+qscaled pipe", 1 | 4 | 8 | 16, True))
     if os.environ.get("FP32", "1") == "1":

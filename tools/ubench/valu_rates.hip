@@ -1,7 +1,15 @@
-// Issue cost of v_exp_f32 / v_add_f32 / v_cvt_pk_bf16_f32 / v_mfma_f32_32x32x16_bf16 for 1..4 waves per SIMD, alone and mixed:
-// cycles per instruction per wave and per SIMD (s_memtime around an unrolled loop).  Diagnostic; hipcc --offload-arch=gfx950.
+// Issue cost of v_exp_f32 / v_add_f32 / v_cvt_pk_bf16_f32 / v_mfma_f32_32x32x16_bf16 for 1..4 waves per SIMD, alone and mixed.
+// Diagnostic; hipcc --offload-arch=gfx950.
+//
+// Metric (round 3; the round-2 version printed mean(per-wave t1 - t0) / waves, which under oldest-first arbitration is 2/3 of the
+// truth at three waves and read "20 cycles per MFMA per SIMD", above the part's peak): one block per CU of 4 w waves, i.e. w waves on
+// each SIMD; every wave stamps s_memtime after a block barrier (t0) and after its loop (t1); the block's MAKESPAN is
+// max(t1) - min(t0) over its waves, in which each SIMD ran w x iters iterations.  Printed: the median over the 256 blocks of
+// makespan / (iters x w x per_iter) = cycles per instruction (or per iteration) PER SIMD, next to mean(t1 - t0) / (iters x per_iter),
+// what one wave waits for its own instruction.  Check: "mfma alone" must read ~32 per SIMD at every occupancy.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -15,7 +23,9 @@ __global__ void k(float* out, long long* cyc, int iters) {
   for (int i = 0; i < 16; ++i) w[i] = threadIdx.x * 2e-3f + i;
   bf16x8 a = {}, b = {};
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.01f); b[i] = (__bf16)(i * 0.1f); }
+  __syncthreads();
   long long t0 = __builtin_readcyclecounter();
+  if (KIND < 10)
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -54,7 +64,7 @@ __global__ void k(float* out, long long* cyc, int iters) {
       }
     }
   }
-  if (KIND >= 10) {
+  if (KIND >= 10 && KIND < 20) {
     // phase structure of an attention tile, no in-wave interleave: 16 MFMAs (two accumulators), then 96 plain + 32 exp2
     // (KIND 10), or 96 plain only (11), or the MFMAs only (12): do co-resident waves overlap each other's phases?
     for (int it = 0; it < iters; ++it) {
@@ -80,7 +90,7 @@ __global__ void k(float* out, long long* cyc, int iters) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (KIND >= 20) {
+  if (KIND >= 20 && KIND < 30) {
     // the non-ALU ingredients of an attention tile, per iteration: 20 = 8 ds_read_b128 + 16 ds_read_b64 (consumed by a cheap xor),
     // 21 = 64 dependent s_add, 22 = 4 global_load_lds_dwordx4 (1 KiB each, L2-resident source) with a counted wait,
     // 23 = one s_barrier, 24 = 8 untaken branches on a VALU compare (v_cmp + s_cbranch_vccnz)
@@ -123,26 +133,77 @@ __global__ void k(float* out, long long* cyc, int iters) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     v[0] += (float)(vx + sacc);
   }
+  if (KIND >= 30) {
+    // the 64-query-rows-per-wave attention tile as an instruction mix: per iteration 32 MFMAs, each followed by its gap's fillers.
+    // 30: 2 exp2 + 4 plain per gap (the full softmax of two 32-row tiles: 64 exp2 + 128 plain);  31: 2 exp2 + 2 plain per gap
+    // (row sums on the matrix pipe, no row maximum);  32: as 30 with 4 accumulators round-robin;  33: 1 exp2 + 2 plain per gap
+    // (what a head_dim-128 kernel has per MFMA)
+    f32x16 acc3 = {}, acc4 = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (KIND == 32) {
+          if ((i & 3) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+          if ((i & 3) == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          if ((i & 3) == 2) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc3, 0, 0, 0);
+          if ((i & 3) == 3) acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc4, 0, 0, 0);
+        } else {
+          if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        const int j = i & 15;
+        v[j] = __builtin_amdgcn_exp2f(v[j]);
+        w[j] = w[j] + 1.25f;
+        w[(j + 5) & 15] = w[(j + 5) & 15] * 0.75f;
+        if (KIND != 33) v[(j + 8) & 15] = __builtin_amdgcn_exp2f(v[(j + 8) & 15]);
+        if (KIND == 30 || KIND == 32) {
+          w[(j + 9) & 15] = w[(j + 9) & 15] + 0.5f;
+          w[(j + 13) & 15] = w[(j + 13) & 15] * 1.5f;
+        }
+        // one MFMA and its fillers per scheduling group, in this order
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, KIND == 33 ? 3 : (KIND == 31 ? 4 : 6), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int i = 0; i < 16; ++i) v[i] += acc3[i] + acc4[i];
+  }
   long long t1 = __builtin_readcyclecounter();
   float s = 0;
   for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc2[i] + w[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (threadIdx.x % 64 == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+  if (threadIdx.x % 64 == 0) {
+    cyc[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)] = t0;
+    cyc[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) + 1] = t1;
+  }
 }
 
 template <int KIND>
 void run(const char* name, int per_iter) {
   float* out; long long* cyc;
-  hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8192 * 8);
+  hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 2 * 8192 * 8);
   for (int wps = 1; wps <= 4; ++wps) {      // waves per SIMD: block of 256*wps threads, one block per CU
     const int threads = 256 * wps, iters = 200;
     hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
     hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
     hipDeviceSynchronize();
-    std::vector<long long> h(256 * threads / 64);
+    const int wpb = threads / 64;
+    std::vector<long long> h(2 * 256 * wpb);
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-    double s = 0; for (auto c : h) s += c; s /= h.size();
-    printf("%-28s %d waves/SIMD: %.1f cycles per instruction per wave, %.1f per SIMD\n", name, wps, s / (iters * per_iter), s / (iters * per_iter * wps));
+    double own = 0;
+    std::vector<double> span(256);
+    for (int b = 0; b < 256; ++b) {
+      long long lo = h[2 * b * wpb], hi = h[2 * b * wpb + 1];
+      for (int w = 0; w < wpb; ++w) {
+        const long long a0 = h[2 * (b * wpb + w)], a1 = h[2 * (b * wpb + w) + 1];
+        lo = a0 < lo ? a0 : lo; hi = a1 > hi ? a1 : hi; own += (double)(a1 - a0);
+      }
+      span[b] = (double)(hi - lo);
+    }
+    own /= 256.0 * wpb;
+    std::sort(span.begin(), span.end());
+    printf("%-52s %d waves/SIMD: %8.1f cycles per SIMD (block makespan / (iters x waves per SIMD)), %8.1f waited by a wave\n", name, wps,
+           span[128] / ((double)iters * per_iter * wps), own / ((double)iters * per_iter));
   }
 }
 int main() {
@@ -161,5 +222,9 @@ int main() {
   run<13>("phase: 96 plain + 32 exp2 (per iteration)", 1);
   run<11>("phases: 16 mfma | 96 plain (per iteration)", 1);
   run<10>("phases: 16 mfma | 96 plain + 32 exp2 (per iteration)", 1);
+  run<30>("32 x (mfma, 2 exp2, 4 plain) (per mfma)", 32);
+  run<32>("32 x (mfma, 2 exp2, 4 plain), 4 acc (per mfma)", 32);
+  run<31>("32 x (mfma, 2 exp2, 2 plain) (per mfma)", 32);
+  run<33>("32 x (mfma, 1 exp2, 2 plain) (per mfma)", 32);
   return 0;
 }
