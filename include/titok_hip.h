@@ -179,9 +179,10 @@ int ttv_decoder_embed(const void* codes, int token_size, const void* w, const vo
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 /* The same operator (transformer.py:100,103) on the 64-query-rows-per-wave kernel: bf16, head_dim 64, q pre-scaled (flags must carry
- * TTV_ATTN_QSCALED; TTV_ATTN_GATE as above).  One workgroup = 4 waves, one per SIMD, each with 64 query rows (two 32-row tiles that
+ * TTV_ATTN_QSCALED; TTV_ATTN_GATE as above).  One workgroup = 4 waves (two workgroups per CU), each wave with 64 query rows (two 32-row tiles that
  * share every K / V fragment read) of any q-head of ONE (sequence, kv-head).  items: device int32 [n_items, 8] =
- * (sequence id, kv-head, wave 0..3: q-head | (first query row / 64) << 8, or -1 for an idle wave, 0, 0); sequence id -1 = padding.
+ * (sequence id, kv-head, wave 0..3: q-head | (first query row / 64) << 8, or -1 for an idle wave, cu_seqlens[sequence], sequence length);
+ * sequence id -1 = padding.
  * The host orders the table so that entries i, i+8, ... (one XCD under round-robin dispatch) share a (sequence, kv-head). */
 int ttv_attention64(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* items, int n_items,
                     int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);

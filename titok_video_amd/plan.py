@@ -256,7 +256,8 @@ class BatchPlan:
 
     def attention_table64(self, q_heads: int, kv_heads: int) -> torch.Tensor:
         """int32 [n,8] work table of ttv_attention64 (the 64-query-rows-per-wave kernel): one entry per workgroup =
-        (sequence, kv-head, 4 x wave item, 0, 0); a wave item is q-head | (first query row // 64) << 8, or -1 for an idle wave.
+        (sequence, kv-head, 4 x wave item, first packed row of the sequence, its length); a wave item is
+        q-head | (first query row // 64) << 8, or -1 for an idle wave.
 
         All wave items of one (sequence, kv-head) unit - every 64-row slice of every q-head of the group - read the same K / V, so a
         unit's items are dealt four at a time to workgroups (the four waves of a workgroup share each K / V tile through LDS) and the
@@ -273,7 +274,7 @@ class BatchPlan:
                 for kvh in range(kv_heads):
                     items = [(kvh * rep + r) | (q << 8) for q in range(n64) for r in range(rep)]
                     items += [-1] * (-len(items) % 4)
-                    units.append([(b, kvh, *items[i:i + 4], 0, 0) for i in range(0, len(items), 4)])
+                    units.append([(b, kvh, *items[i:i + 4], self.cu_seqlens[b], s) for i in range(0, len(items), 4)])
             order = sorted(range(len(units)), key=lambda i: len(units[i]), reverse=True)
             lists, weight = [[] for _ in range(8)], [0] * 8
             for i in order:

@@ -32,8 +32,8 @@ out = torch.empty(L, dm, dtype=torch.bfloat16, device=DEV)
 n_samples = (table.shape[0] + 36) // 37
 stamps = torch.zeros(n_samples * 4 * 8, dtype=torch.int64, device=DEV)
 lib.ttv_debug_stamps(stamps.data_ptr())
-NAMES = ["own DMA wait (vmcnt)", "barrier", "Ya: 4 PV_B | rowmax A + DMA issue", "Yb: 4 PV_B + 8 S_B | exp A + V reads", "Xa: 4 PV_A | rowmax B + K reads",
-         "Xb: 4 PV_A + 8 S_A | exp B"]
+NAMES = ["DMA wait (vmcnt) + barrier", "Ya x2: 4 PV_B | rowmax A (+1 DMA)", "Yb x2: 4 S_B | exp A + V reads", "Xa x2: 4 PV_A | rowmax B + K reads (+1 DMA)",
+         "Xb x2: 4 S_A | exp B", "-"]
 for _ in range(3):
     _lib.check(lib.ttv_attention64(qkv.data_ptr(), ld, out.data_ptr(), dm, plan.cu_dev.data_ptr(), table.data_ptr(), table.shape[0], HQ, HKV, 64, 1 | 4, 0, ST),
                "attn64")
