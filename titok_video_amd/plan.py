@@ -302,9 +302,12 @@ class BatchPlan:
         # the grid coarser: the launch alone is 10 % slower)
         paired = 1 if (q_heads // kv_heads) % 2 == 0 and os.environ.get("TTV_ATTN_PAIRED", "0") == "1" else 0
         all_full = 1 if self._attn_all_full.get(t.data_ptr()) else 0
-        # the 64-rows-per-wave kernel (one wave per SIMD) for inference towers with pre-scaled q; TTV_ATTN64=0 keeps the
-        # 32-rows-per-wave kernel everywhere (A/B measurements)
-        t64 = self.attention_table64(q_heads, kv_heads) if (q_heads <= 255 and os.environ.get("TTV_ATTN64", "1") != "0") else None
+        # the 64-rows-per-wave kernel (ttv_attention64) for inference towers with pre-scaled q: OPT-IN (TTV_ATTN64=1).  Measured in
+        # round 3: its key loop needs 2 100 cycles per SIMD for a 64-row x 64-key step against 3 800 for the
+        # 32-rows-per-wave kernel, but at the benchmark batch (576 workgroups on 512 resident slots, 18 key tiles each) the launch is
+        # 77 us against 60 us: a block's prologue + epilogue are 18 % of its life and the 64 workgroups beyond the resident slots run
+        # a second, nearly empty round; at S = 9216 both kernels reach the same 0.37-0.40 of the MFMA peak.
+        t64 = self.attention_table64(q_heads, kv_heads) if (q_heads <= 255 and os.environ.get("TTV_ATTN64", "0") == "1") else None
         return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
                           items64=t64.data_ptr() if t64 is not None else None, n_items64=int(t64.shape[0]) if t64 is not None else 0,
                           **self._base_fields)
