@@ -37,6 +37,8 @@ extern "C" {
 #define TTV_DECODER 1
 
 #define TTV_MAX_FSQ 8
+#define TTV_MAX_TOKEN 64       /* widest latent token (encoder proj_out rows / decoder proj_in columns): FSQ needs <= TTV_MAX_FSQ, the
+                                  nearest-codebook-entry quantiser of BASELINE configs #4 / #5 uses 32 / 64 */
 #define TTV_MAX_CLIPS_PER_LAUNCH 64
 
 const char* ttv_error_string(void);
@@ -207,7 +209,8 @@ typedef struct ttv_tower_dims {
   int32_t inner;         /* GEGLU hidden I                      transformer.py:39-40 */
   int32_t patch_t, patch_h, patch_w;
   int32_t pix_channels;  /* 3 */
-  int32_t token_size;    /* len(fsq_levels) (encoder out / decoder in); 1 for the discriminator use */
+  int32_t token_size;    /* len(fsq_levels) (encoder out / decoder in); 1 for the discriminator use; up to TTV_MAX_TOKEN for inference
+                            towers in front of / behind ttv_vq_l2_argmin (the training entry points take <= TTV_MAX_FSQ) */
   float eps;             /* RMSNorm eps 1e-5 */
   float alpha;           /* KEEL residual scale 2*layers        transformer.py:117 */
 } ttv_tower_dims;

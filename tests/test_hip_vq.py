@@ -106,3 +106,57 @@ def test_l2_quantizer_module_straight_through():
     w = torch.randn_like(codes)
     (codes * w).sum().backward()
     assert torch.equal(z.grad, w)                      # d codes / d z = identity (straight-through)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(8192, 32), (1024, 64)])
+def test_titok_with_l2_quantizer_wired_in(dtype, shape):
+    """`quantizer: l2` (build-defined, NOT reference-pinned: the reference ships FSQ only, titok.py:37): encode -> nearest codebook
+    entry -> straight-through lookup -> decode through `TiTok.forward`, token widths 32 / 64 (the widths of BASELINE configs #4 / #5),
+    against the oracle towers + the cdist oracle.  float32 towers: every index whose runner-up is further than the fp32 rounding of the
+    towers is the oracle's, pixels follow; bf16: the decoder is judged on the indices the HIP encoder produced, and the share of
+    indices equal to the fp32 oracle's is reported against what a bf16 execution of the oracle towers gets."""
+    from types import SimpleNamespace
+    from oracle import titok_oracle as O
+    from titok_video_amd.model.titok import TiTok
+    from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
+    n_entries, width = shape
+    cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(
+        patch_size=[4, 8, 8], fsq_levels=None, quantizer="l2", codebook_size=n_entries, token_size=width, encoder_size="tiny", decoder_size="tiny")))
+    sd = seeded_titok_state(3, token_size=width)
+    model = TiTok(cfg)
+    cb = torch.randn(n_entries, width, generator=torch.Generator().manual_seed(9)) * 1.5
+    model.load_state_dict({**sd, "quantize.codebook": cb}, strict=True)
+    shapes, counts = [(8, 32, 48), (4, 16, 16), (16, 64, 64)], [17, 1, 128]
+    cpu_clips = synthetic_clips(shapes, seed=5)
+    with torch.no_grad():
+        z_ref = O.encoder_forward(cpu_clips, counts, sd, "tiny", prefix="encoder.")
+    idx_ref, _, gap = V.l2_argmin(z_ref, cb)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    model = model.to(DEV, tdt).eval()
+    clips = [c.to(DEV, tdt) for c in cpu_clips]
+    with torch.no_grad():
+        recon, info = model(clips, counts)
+        codes, info2 = model.encode(clips, counts, split_indices=True)
+    idx = info["indices"].cpu()
+    assert torch.equal(torch.cat(list(info2["indices"])).cpu(), idx) and codes.shape == (sum(counts), width)
+    if dtype == "f32":
+        safe = gap > 1e-3 * (1.0 + z_ref.double().pow(2).sum(1).sqrt())      # runner-up beyond the towers' fp32 rounding
+        assert int(safe.sum()) > 0.9 * idx.numel()
+        assert torch.equal(idx[safe], idx_ref[safe])
+    else:
+        with torch.no_grad():    # the bf16 yardstick: the oracle towers run in bf16 on the same inputs
+            z_y = O.encoder_forward([c.to(torch.bfloat16) for c in cpu_clips], counts, sd, "tiny", prefix="encoder.")
+        idx_y, _, _ = V.l2_argmin(z_y.float(), cb)
+        agree, agree_y = float((idx == idx_ref).float().mean()), float((idx_y == idx_ref).float().mean())
+        print(f"l2 {shape}: bf16 HIP indices equal to the fp32 oracle's {agree:.3f}, bf16 oracle towers {agree_y:.3f}")
+        assert agree >= agree_y - 0.08
+    # decoder on the indices the HIP encoder produced (lookup of the same codebook rows)
+    with torch.no_grad():
+        dec_ref = O.decoder_forward(cb[idx.long()], counts, shapes, sd, "tiny", prefix="decoder.")
+        again = model.decode_indices(info["indices"], shapes, counts)
+    tol = 5e-3 if dtype == "f32" else 0.25
+    for r, a, ref in zip(recon, again, dec_ref):
+        assert float((r.float().cpu() - ref).abs().max()) < tol
+        assert torch.equal(r, a)

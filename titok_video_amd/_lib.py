@@ -14,6 +14,7 @@ import torch
 TTV_BF16, TTV_F32 = 0, 1
 TTV_ENCODER, TTV_DECODER = 0, 1
 TTV_MAX_FSQ = 8
+TTV_MAX_TOKEN = 64
 TTV_MAX_CLIPS_PER_LAUNCH = 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -76,7 +76,7 @@ static int check_dims(const ttv_tower_dims* d, const ttv_batch* b) {
   TTV_CHECK_ARG(d->head_dim == 64 && d->width == d->q_heads * 64, "width must be q_heads*64");
   TTV_CHECK_ARG(d->width % 64 == 0 && d->width <= 1024, "width %d unsupported", d->width);
   TTV_CHECK_ARG(d->inner % 32 == 0, "GEGLU inner dim must be a multiple of 32");
-  TTV_CHECK_ARG(d->token_size >= 1 && d->token_size <= TTV_MAX_FSQ, "token_size out of range");
+  TTV_CHECK_ARG(d->token_size >= 1 && d->token_size <= TTV_MAX_TOKEN, "token_size out of range");
   TTV_CHECK_ARG(((int64_t)d->pix_channels * d->patch_t * d->patch_h * d->patch_w) % 8 == 0, "patch vector length must be a multiple of 8");
   TTV_CHECK_ARG(b->n_clips > 0 && b->total_rows == b->sum_tokens + b->sum_patches, "inconsistent batch");
   return TTV_OK;

@@ -175,7 +175,8 @@ int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int ro
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decoder latent rows: RMSNorm_t(proj_in(codes) + bias + mask_token) (blocks.py:125,166).  K = token_size <= 8.
+// Decoder latent rows: RMSNorm_t(proj_in(codes) + bias + mask_token) (blocks.py:125,166).  token_size <= TTV_MAX_FSQ keeps the code
+// row in registers; wider tokens (<= TTV_MAX_TOKEN, the L2 quantiser's) re-read it from the cache in the feature loop.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, int C, const T* __restrict__ w /*[d,C]*/,
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, 
   float cz[TTV_MAX_FSQ];
 #pragma unroll
   for (int c = 0; c < TTV_MAX_FSQ; ++c) cz[c] = c < C ? Cvt<T>::to_f(codes[(size_t)r * C + c]) : 0.f;
+  const T* crow = codes + (size_t)r * C;
   const float m = round_to<T>(mask_token[0]);
   float v[MAX_ITERS][4];
   float ss = 0.f;
@@ -198,7 +200,13 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, 
       const int f = (it * 64 + lane) * 4 + e;
       float h = 0.f;
       if (f < d) {
-        for (int c = 0; c < C; ++c) h += cz[c] * Cvt<T>::to_f(w[(size_t)f * C + c]);
+        if (C <= TTV_MAX_FSQ) {
+#pragma unroll
+          for (int c = 0; c < TTV_MAX_FSQ; ++c)
+            if (c < C) h += cz[c] * Cvt<T>::to_f(w[(size_t)f * C + c]);
+        } else {
+          for (int c = 0; c < C; ++c) h += Cvt<T>::to_f(crow[c]) * Cvt<T>::to_f(w[(size_t)f * C + c]);
+        }
         h = round_to<T>(h + Cvt<T>::to_f(bias[f]));  // nn.Linear output in dtype
         h = round_to<T>(h + m);                      // + mask_token.to(dtype)
       }
@@ -230,7 +238,7 @@ int ttvk_dec_embed(const void* codes, int C, const void* w, const void* bias, co
 int ttvk_dec_embed_ex(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain, void* x,
                       int dtype, int ld, const int* rows_map, int rows, int d, float eps, void* hpre, hipStream_t s) {
   if (rows == 0) return TTV_OK;
-  TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_FSQ, "dec_embed: token_size %d out of range", C);
+  TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_TOKEN, "dec_embed: token_size %d out of range", C);
   TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "dec_embed: width");
   dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
   if (dtype == TTV_BF16)
@@ -369,6 +377,8 @@ __global__ __launch_bounds__(256) void k_enc_tail(const T* __restrict__ x, int l
     }
   }
   float zc[TTV_MAX_FSQ];
+#pragma unroll
+  for (int c = 0; c < TTV_MAX_FSQ; ++c) zc[c] = 0.f;
   for (int c = 0; c < C; ++c) {
     float acc = 0.f;
 #pragma unroll
@@ -379,13 +389,18 @@ __global__ __launch_bounds__(256) void k_enc_tail(const T* __restrict__ x, int l
         acc += v[it][0] * wv[0] + v[it][1] * wv[1] + v[it][2] * wv[2] + v[it][3] * wv[3];
       }
     }
-    zc[c] = wave_sum(acc) + Cvt<T>::to_f(bias[c]);
+    const float zv = wave_sum(acc) + Cvt<T>::to_f(bias[c]);
+    if (lane == 0 && z_out) z_out[(size_t)r * C + c] = zv;
+    if (have_fsq) {                 // C <= TTV_MAX_FSQ (checked by the host): static register indices
+#pragma unroll
+      for (int k = 0; k < TTV_MAX_FSQ; ++k)
+        if (k == c) zc[k] = zv;
+    }
   }
-  if (lane == 0) {
+  if (lane == 0 && have_fsq) {
     float idx = 0.f;
     for (int c = 0; c < C; ++c) {
-      if (z_out) z_out[(size_t)r * C + c] = zc[c];
-      if (have_fsq) {
+      {
         float b, code;
         idx = __fadd_rn(idx, fsq_channel(p, c, zc[c], &b, &code));
         codes[(size_t)r * C + c] = Cvt<T>::from_f(code);
@@ -400,7 +415,7 @@ int ttvk_enc_tail(const void* x, int dtype, int ld, const int* rows_map, int row
                   const void* w, const void* bias, int C, const ttv_fsq_params* fsq, float* z_out, void* codes, int* indices,
                   float* bounded, hipStream_t s) {
   if (rows == 0) return TTV_OK;
-  TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_FSQ, "enc_tail: token_size %d out of range", C);
+  TTV_CHECK_ARG(C >= 1 && C <= (fsq ? TTV_MAX_FSQ : TTV_MAX_TOKEN), "enc_tail: token_size %d out of range", C);
   TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "enc_tail: width");
   TTV_CHECK_ARG(!fsq || fsq->n == C, "enc_tail: fsq dim != token_size");
   FsqDev p;

@@ -6,7 +6,11 @@ types and state-dict keys (`encoder.*`, `decoder.*`; FSQ has no persistent keys)
   * `encode(..., split_indices=True)` works (it raises TypeError upstream) and returns a tuple
     of per-clip index tensors;
   * the encoder tail and FSQ are one kernel, with the pre-quantisation tokens kept in fp32 (the reference rounds
-    them to bf16 under autocast before `z.float()`, fsq.py:128).
+    them to bf16 under autocast before `z.float()`, fsq.py:128);
+  * BUILD-DEFINED, NOT REFERENCE-PINNED: `config.tokenizer.model.quantizer = "l2"` (with `codebook_size`, `token_size`) wires the
+    nearest-codebook-entry quantiser of BASELINE.json's configs #4 / #5 (8192 x 32, 16384 x 64) into the one quantiser slot the
+    reference has (titok.py:37,47-52): encode -> L2 argmin + straight-through lookup -> decode.  The reference itself ships FSQ only;
+    the default (`quantizer` absent or "fsq") is the reference's model.  Inference only (the training towers take FSQ-sized tokens).
 """
 from __future__ import annotations
 
@@ -17,6 +21,7 @@ from ..plan import host_ints
 from .base.blocks import TiTokDecoder, TiTokEncoder
 from .base.utils import init_weights
 from .quantizer.fsq import FSQ
+from .quantizer.vq_l2 import L2Quantizer
 
 
 class TiTok(nn.Module):
@@ -26,15 +31,24 @@ class TiTok(nn.Module):
         super().__init__()
         self.config = config
         m = config.tokenizer.model
-        fsq_levels = [int(v) for v in m.fsq_levels]
         patch = tuple(int(p) for p in m.patch_size)
-        n_code = len(fsq_levels)                       # one latent channel per FSQ level
+        self.quantizer_kind = str(getattr(m, "quantizer", "fsq")).lower()
+        if self.quantizer_kind == "fsq":
+            fsq_levels = [int(v) for v in m.fsq_levels]
+            n_code = len(fsq_levels)                   # one latent channel per FSQ level
+            quantize = FSQ(levels=fsq_levels)
+        elif self.quantizer_kind == "l2":
+            n_code, n_entries = int(m.token_size), int(m.codebook_size)
+            g = torch.Generator().manual_seed(int(getattr(m, "codebook_seed", 0)))
+            quantize = L2Quantizer(torch.randn(n_entries, n_code, generator=g))     # synthetic start; `quantize.codebook` is a Parameter
+        else:
+            raise ValueError(f"tokenizer.model.quantizer must be 'fsq' or 'l2', got {self.quantizer_kind!r}")
         towers = dict(encoder=TiTokEncoder(model_size=m.encoder_size, patch_size=patch, in_channels=3, out_channels=n_code),
-                      quantize=FSQ(levels=fsq_levels),
+                      quantize=quantize,
                       decoder=TiTokDecoder(model_size=m.decoder_size, patch_size=patch, in_channels=n_code, out_channels=3))
         for name, mod in towers.items():               # registration order = the reference's state-dict order
             setattr(self, name, mod)
-        self.apply(init_weights)
+        self.apply(init_weights)                       # nn.Linear / RMSNorm only: the L2 codebook keeps its start values
         self.last_bounded = None   # fp32 FSQ pre-rounding values of the last encode(want_bounded=True)
 
     # ---- encode ---------------------------------------------------------------------------------------------------------
@@ -49,6 +63,15 @@ class TiTok(nn.Module):
 
     def encode(self, x, token_counts, grids=None, split_indices=False, want_bounded=False):
         counts = host_ints(token_counts)
+        if self.quantizer_kind == "l2":
+            if self.encoder._wants_grad(*x):
+                raise NotImplementedError("the L2-quantiser wiring is an inference path (the training towers take token_size <= 8)")
+            z = self.encoder.run(x, counts, grids, None, want_z=True)["z"]          # fp32 [sum K, token_size]
+            codes, info = self.quantize(z.to(x[0].dtype))
+            self.last_bounded = None
+            if split_indices:
+                info["indices"] = torch.split(info["indices"], counts, dim=0)
+            return codes, info
         if self.encoder._wants_grad(*x):
             return self._encode_differentiable(x, counts, grids, split_indices)
         res = self.encoder.run(x, counts, grids, self.quantize.params, want_z=False, want_bounded=want_bounded)
@@ -68,6 +91,8 @@ class TiTok(nn.Module):
         # reference: decoder parameter dtype (titok.py:61); under autocast (Lightning bf16-mixed, fp32 masters)
         # the towers compute in the autocast dtype, so follow it
         compute_dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else next(self.decoder.parameters()).dtype
+        if self.quantizer_kind == "l2":
+            return self.decode(self.quantize.lookup(indices, compute_dtype), token_counts, grids)
         return self.decode(self.quantize.indices_to_codes(indices, dtype=compute_dtype), token_counts, grids)
 
     def forward(self, x, token_counts):
