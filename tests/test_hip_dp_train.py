@@ -208,3 +208,52 @@ def test_two_rank_training_step_over_rccl_equals_single_process():
             for n, v in params.items():
                 err = float((torch.from_numpy(v) - ref[n]).norm() / (ref[n].norm() + 1e-30))
                 assert err < 1e-5, (rank, overlap, n, err)
+
+
+def test_communication_stream_path_on_one_gpu_defers_gradients():
+    """the non-gloo branch of dp.GradReducer (communication stream, per-layer events, gradients produced on that
+    stream) never ran on the one-GPU boxes.  `simulate=True` runs exactly that branch without a process group (the collective of a
+    world of one is the identity).  Checked here: (1) the tower gradients are NOT handed to autograd (p.grad stays None until
+    finish()), (2) finish() delivers them behind the stream join, equal to the plain backward's up to the fp32 kernels' atomic-order
+    noise, (3) a gradient that is already there is accumulated into, not overwritten or raced with (micro-batch accumulation)."""
+    from titok_video_amd import dp
+    from titok_video_amd.synthetic import synthetic_clips
+    from titok_video_amd.train import _towers, l1_reconstruction_loss
+    clips = synthetic_clips(SHAPES + [(4, 16, 16)], seed=77, dtype=torch.float32, device="cuda:0")
+    counts = COUNTS + [4]                                   # 4 clips: count * g / count is exact in fp32
+
+    def backward(model, red):
+        towers = _towers(model)
+        if red is not None:
+            red.attach(*towers)
+            red.begin_step(len(clips))
+        try:
+            recon, _ = model(clips, counts)
+            l1_reconstruction_loss(recon, clips).backward()
+        finally:
+            if red is not None:
+                red.detach(*towers)
+
+    plain = _model()
+    backward(plain, None)
+    torch.cuda.synchronize()
+    ref = {n: p.grad.clone() for n, p in plain.named_parameters()}
+
+    model = _model()
+    red = dp.GradReducer("cuda:0", simulate=True)
+    assert red.on_comm_stream
+    backward(model, red)
+    assert all(p.grad is None for p in model.parameters())             # (1) nothing reached autograd's accumulation
+    assert red.slices == 2 * (4 + 1) and len(red._deferred) == 76      # 4 layer slices + head/tail per tower; every parameter deferred
+    red.finish()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():                             # (2)
+        scale = float(ref[n].abs().max()) + 1e-12
+        assert float((p.grad - ref[n]).abs().max()) < 1e-4 * scale, n
+    first = {n: p.grad.clone() for n, p in model.named_parameters()}
+    backward(model, red)                                               # (3) second micro-batch on top of existing gradients
+    red.finish()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        scale = float(ref[n].abs().max()) + 1e-12
+        assert float((p.grad - (first[n] + ref[n])).abs().max()) < 2e-4 * scale, n

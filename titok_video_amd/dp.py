@@ -65,16 +65,26 @@ class GradReducer:
     staged through the host - which synchronises, so nothing overlaps there; the results are bit-identical to RCCL's order of
     operations (multiply, sum over ranks, divide) and to `allreduce_mean_by_count`."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, simulate: bool = False):
+        """simulate=True (tests on one GPU, no process group): the communication-stream path runs exactly as under RCCL - events,
+        stream hand-over, deferred gradients - with the collective itself left out (world size 1: it would be the identity)."""
         self.device = torch.device(device)
         self.group = group
         self.rank, self.world = world()
+        self.simulate = bool(simulate) and self.world == 1
         self.gloo = self.world > 1 and dist.get_backend(group) == "gloo"
         self.comm = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._local = None      # fp32 device scalar: this rank's clip count
         self._total = None      # fp32 device scalar: the global clip count
         self.bytes_reduced = 0
         self.slices = 0
+        self._deferred = []     # (parameter, gradient produced on the communication stream): assigned in finish()
+        self.reduced_ids = set()   # id() of every parameter whose gradient went through this reducer in the current step
+
+    @property
+    def on_comm_stream(self) -> bool:
+        """True when slices are reduced asynchronously on the communication stream (RCCL, or the one-GPU simulation)."""
+        return self.comm is not None and ((self.world > 1 and not self.gloo) or self.simulate)
 
     def attach(self, *towers) -> None:
         for t in towers:
@@ -86,6 +96,13 @@ class GradReducer:
 
     def begin_step(self, local_count: int) -> None:
         self.bytes_reduced, self.slices = 0, 0
+        self._deferred, self.reduced_ids = [], set()
+        if self.simulate:
+            self.comm.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm):
+                self._local = torch.full((), float(local_count), dtype=torch.float32, device=self.device)
+                self._total = self._local.clone()
+            return
         if self.world == 1:
             return
         if self.gloo:
@@ -103,7 +120,7 @@ class GradReducer:
 
     def reduce_slice(self, flat: torch.Tensor, lo: int, hi: int, ready: "torch.cuda.Event") -> None:
         """In place on flat[lo:hi] (fp32), after `ready`, on the communication stream."""
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.simulate) or hi <= lo:
             return
         sl = flat[lo:hi]
         self.bytes_reduced += 4 * (hi - lo)
@@ -118,7 +135,8 @@ class GradReducer:
         self.comm.wait_event(ready)
         with torch.cuda.stream(self.comm):
             sl.mul_(self._local)
-            dist.all_reduce(sl, group=self.group)
+            if not self.simulate:
+                dist.all_reduce(sl, group=self.group)
             sl.div_(self._total)
         flat.record_stream(self.comm)
 
@@ -126,13 +144,37 @@ class GradReducer:
         """Context in which a tower turns its reduced flat buffer into per-parameter gradients (casts / permutations run behind
         the reductions on the communication stream instead of making the compute stream wait for them)."""
         import contextlib
-        if self.world == 1 or self.gloo or self.comm is None:
+        if not self.on_comm_stream:
             return contextlib.nullcontext()
         return torch.cuda.stream(self.comm)
 
+    def defer(self, pairs) -> None:
+        """(parameter, gradient) pairs whose gradient tensors were produced on the communication stream.  They are NOT handed to
+        autograd (its AccumulateGrad runs on the compute stream without waiting for this one: any real accumulation - p.grad already
+        set, a tower used twice in one backward, a tensor hook - would read the slice while the all-reduce is still writing it);
+        `finish()` assigns / accumulates them behind the stream join."""
+        self._deferred.extend(pairs)
+
     def finish(self) -> None:
-        if self.world > 1 and not self.gloo and self.comm is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm)
+        """Join the communication stream into the current one, then deliver the deferred gradients (p.grad = g, or p.grad += g when a
+        gradient is already there - micro-batch accumulation, zero_grad(set_to_none=False))."""
+        if self.on_comm_stream:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.comm)
+            for p, g in self._deferred:
+                g.record_stream(cur)
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+        self._deferred = []
+
+    def reduce_rest(self, params, local_count: int) -> None:
+        """Gradients of trainable parameters that did NOT go through the attached towers (e.g. an L2 quantiser's codebook, a future
+        pre-/post-quantiser linear): reduced after the backward in flat buckets, same count-weighted mean.  Call after finish()."""
+        rest = [p.grad for p in params if p.grad is not None and id(p) not in self.reduced_ids]
+        if rest and self.world > 1:
+            allreduce_mean_by_count(rest, local_count, group=self.group)
 
 
 def allreduce_mean_by_count(grads: Iterable[torch.Tensor], local_count: int, group=None, bucket_bytes: int = 64 << 20) -> int:

@@ -260,10 +260,13 @@ class _Tower(nn.Module):
         red.reduce_slice(flat, 0, offs[8], tail)       # proj_in / mask_token / ln_pre / ln_post / proj_out
         with red.stream():
             out = self._finish_grads(flat)
-        if red.comm is not None and red.world > 1 and not red.gloo:
-            cur = torch.cuda.current_stream(flat.device)
-            for g in out.values():
-                g.record_stream(cur)               # produced on the communication stream, consumed on the compute stream after finish()
+        params = self._grad_layout()[0]
+        red.reduced_ids.update(id(p) for p in params)
+        if red.on_comm_stream:
+            # produced on the communication stream: never handed to autograd (its AccumulateGrad does not wait for that stream);
+            # the reducer assigns them to p.grad in finish(), behind the stream join
+            red.defer([(p, out[id(p)]) for p in params if p.requires_grad and id(p) in out])
+            return {}
         return out
 
     def _finish_grads(self, flat: torch.Tensor):

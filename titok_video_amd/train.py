@@ -110,9 +110,11 @@ def training_step(model, clips: List[torch.Tensor], token_counts, optimizer, max
     finally:
         if red is not None:
             red.detach(*towers)
+    if red is not None:
+        red.finish()                                   # joins the communication stream and delivers the towers' gradients
     params = [p for p in model.parameters() if p.grad is not None]
     if red is not None:
-        red.finish()
+        red.reduce_rest(params, len(clips))            # trainable parameters outside the towers (none in the reference's TiTok)
     else:
         dp.allreduce_mean_by_count([p.grad for p in params], len(clips), group=group)
     gnorm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
@@ -213,9 +215,11 @@ def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_count
     finally:
         if red is not None:
             red.detach(*g_towers)
-    g_params = [p for p in model.parameters() if p.grad is not None]
     if red is not None:
         red.finish()
+    g_params = [p for p in model.parameters() if p.grad is not None]
+    if red is not None:
+        red.reduce_rest(g_params, len(clips))
     else:
         dp.allreduce_mean_by_count([p.grad for p in g_params], len(clips), group=group)
     if max_grad_norm:
@@ -233,9 +237,11 @@ def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_count
         finally:
             if red is not None:
                 red.detach(*d_towers)
-        d_params = [p for p in loss_module.disc_model.parameters() if p.grad is not None]
         if red is not None:
             red.finish()
+        d_params = [p for p in loss_module.disc_model.parameters() if p.grad is not None]
+        if red is not None:
+            red.reduce_rest(d_params, len(clips))
         else:
             dp.allreduce_mean_by_count([p.grad for p in d_params], len(clips), group=group)
         if max_grad_norm:
