@@ -406,6 +406,11 @@ int ttv_codebook_histogram(const int32_t* indices, int n, int64_t* counts, int c
 int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, const int32_t* sizes, int n_clips, int dtype, float* loss,
                 void* stream);
 
+/* The loader's tail on the device (dataset/video_dataset.py:116-119: ToDtype(scale=True) + Normalize(0.5, 0.5) on channel-first
+ * frames): decoded frames uint8 [T,H,W,3] (device memory, what the decoder / a shard hands over) -> clip [3,T,H,W] in `dtype`,
+ * value u8 / 127.5 - 1 evaluated in fp32 and rounded once.  T*H*W % 4 == 0 (patch-aligned clips always are). */
+int ttv_clip_from_u8(const void* frames_thwc, int T, int H, int W, void* clip_cthw, int dtype, void* stream);
+
 /* PSNR statistic of the evaluation loop (model/metrics/eval_metrics.py:19,32-36: x.clamp(-1, 1), torchmetrics
  * PeakSignalNoiseRatio(data_range=2) = running sum of squared errors + element count): acc[0] += sum (clamp(recon) - target)^2,
  * acc[1] += number of elements, both double, device memory, over the clips of the call (host arrays of device pointers, `dtype`).

@@ -1,0 +1,53 @@
+"""titok_video_amd/loader.py on the CPU: the worker processes' batch stream (uint8 frames in shared memory, token-budget batching with
+the reference's policy, video_dataset.py:130-172) is deterministic and equals what one process computes from the same shards."""
+import os
+
+import numpy as np
+import torch
+
+from titok_video_amd.data import dynamic_batches
+from titok_video_amd.loader import ShardBatchLoader, raw_shard_samples
+from titok_video_amd.shards import shard_samples, write_synthetic_shards
+
+
+def _take(it, n):
+    out = []
+    for b in it:
+        out.append(b)
+        if len(out) == n:
+            break
+    return out
+
+
+def test_worker_batches_are_deterministic_and_match_one_process(tmp_path):
+    paths = write_synthetic_shards(str(tmp_path), 4, 16, min_grid=(4, 16, 16), max_grid=(8, 32, 32), seed=3)
+    kw = dict(patch=(4, 8, 8), token_range=(1, 16), seq_len=96, seed=7, epochs=1, drop_last=True)
+    runs = []
+    for _ in range(2):
+        ld = ShardBatchLoader(paths, rank=1, world_size=2, workers=2, **kw).start()
+        runs.append(list(ld.raw_batches()))
+        ld.close()
+    assert len(runs[0]) == len(runs[1]) > 2
+    for a, b in zip(*runs):
+        assert a["__key__"] == b["__key__"] and a["token_counts"] == b["token_counts"]
+        assert all(torch.equal(x, y) for x, y in zip(a["frames"], b["frames"]))
+    # rank 1 of 2 owns shards 1 and 3; worker 0 reads shard 1, worker 1 shard 3 (seeds 7 and 7 + 1009); batches alternate
+    mine = [p for i, p in enumerate(sorted(paths)) if i % 2 == 1]
+    per_worker = [list(dynamic_batches(raw_shard_samples([mine[w]], 1), (4, 8, 8), (1, 16), 96, seed=7 + 1009 * w, drop_last=True)) for w in range(2)]
+    want = []
+    for i in range(max(len(p) for p in per_worker)):
+        for w in range(2):
+            if i < len(per_worker[w]):
+                want.append(per_worker[w][i])
+    assert [b["__key__"] for b in runs[0]] == [b["__key__"] for b in want]
+    for got, ref in zip(runs[0], want):
+        assert got["token_counts"] == ref["token_counts"].tolist()
+        for f, v in zip(got["frames"], ref["video"]):
+            assert f.dtype == torch.uint8 and torch.equal(f.permute(3, 0, 1, 2), v)
+            rows = sum(np.prod([d // p for d, p in zip(v.shape[1:], (4, 8, 8))]) for v in ref["video"]) + sum(got["token_counts"])
+            assert rows <= 96
+    # and the pixel values are those the host-side reader normalises (shards.shard_samples): u8 / 127.5 - 1
+    first = next(iter(shard_samples([mine[0]], dtype=torch.float32)))
+    f0 = per_worker[0][0]["video"][0]
+    assert first["__key__"] == per_worker[0][0]["__key__"][0]
+    assert torch.equal(first["video"], f0.to(torch.float32) / 127.5 - 1.0)

@@ -140,6 +140,7 @@ SYMBOLS = {
     "ttv_codebook_histogram": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ttv_rope_table_build": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "ttv_l1_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "ttv_clip_from_u8": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ttv_sq_err_accumulate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_debug_set": (C.c_int, [C.c_int]),
     "ttv_debug_stamps": (C.c_int, [vp]),

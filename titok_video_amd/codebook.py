@@ -70,11 +70,14 @@ class CodebookLogger(nn.Module):
         dist_on = all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized()
         ready = self.is_score_ready()
         if dist_on:
-            dev = self.codebook_indices[0].device if self.codebook_indices else None
-            if dev is None or torch.distributed.get_backend(self.process_group) == "gloo":
+            # the flag lives where the backend can reduce it: host memory for gloo, this rank's GPU for nccl (= RCCL) - also when the
+            # FIFO is still empty and there is no sample to take the device from
+            if torch.distributed.get_backend(self.process_group) == "gloo":
                 dev = torch.device("cpu")
-            elif dev.type != "cuda":
-                dev = torch.device("cuda", torch.cuda.current_device())
+            else:
+                dev = self.codebook_indices[0].device if self.codebook_indices else None
+                if dev is None or dev.type != "cuda":
+                    dev = torch.device("cuda", torch.cuda.current_device())
             flag = torch.tensor([1 if ready else 0], dtype=torch.int64, device=dev)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
             ready = bool(int(flag.item()))

@@ -486,6 +486,11 @@ int ttv_l1_loss(void* const* recon, void* const* target, void* const* grad, cons
   return TTV_OK;
 }
 
+int ttv_clip_from_u8(const void* frames_thwc, int T, int H, int W, void* clip_cthw, int dtype, void* stream) {
+  TTV_CHECK_ARG(frames_thwc && clip_cthw && T > 0 && H > 0 && W > 0, "clip_from_u8: bad argument");
+  return ttvk_clip_from_u8(frames_thwc, (long long)T * H * W, clip_cthw, dtype, (hipStream_t)stream);
+}
+
 int ttv_sq_err_accumulate(void* const* recon, void* const* target, const int32_t* sizes, int n_clips, int dtype, int clamp, double* acc,
                           void* stream) {
   for (int c0 = 0; c0 < n_clips; c0 += TTV_MAX_CLIPS_PER_LAUNCH) {

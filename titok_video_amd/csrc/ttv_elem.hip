@@ -610,3 +610,45 @@ int ttvk_rope_build(const float* base_cos, const float* base_sin, int n_ids, int
   TTV_CHECK_LAUNCH("rope_build");
   return TTV_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Loader tail on the device (reference dataset/video_dataset.py:116-119: v2.ToDtype(scale=True) + Normalize(0.5, 0.5) after the
+// frames were permuted to channel-first): decoded frames uint8 [T,H,W,3] -> clip [3,T,H,W] in dtype, value u8 / 127.5 - 1 in
+// fp32 (one correctly rounded division, one subtraction: bit-equal to the torch expression the host loader used), rounded once to
+// dtype.  HBM-bound: 3 bytes in, 3 elements out per pixel; a thread takes 4 consecutive pixels (12 bytes in, 3 x 4 elements out).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_clip_from_u8(const uint8_t* __restrict__ frames, T* __restrict__ clip, long long n_pix) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 4 pixels
+  const long long p0 = q * 4;
+  if (p0 >= n_pix) return;
+  if (p0 + 4 <= n_pix) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(frames + p0 * 3);     // 12 bytes, 4-byte aligned (p0 % 4 == 0)
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+    const uint8_t b[12] = {(uint8_t)w0, (uint8_t)(w0 >> 8), (uint8_t)(w0 >> 16), (uint8_t)(w0 >> 24), (uint8_t)w1, (uint8_t)(w1 >> 8),
+                           (uint8_t)(w1 >> 16), (uint8_t)(w1 >> 24), (uint8_t)w2, (uint8_t)(w2 >> 8), (uint8_t)(w2 >> 16), (uint8_t)(w2 >> 24)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = __fsub_rn(__fdiv_rn((float)b[3 * i + c], 127.5f), 1.0f);
+      Vec4<T>::store(clip + (size_t)c * n_pix + p0, v);
+    }
+  } else {
+    for (long long p = p0; p < n_pix; ++p)
+      for (int c = 0; c < 3; ++c) clip[(size_t)c * n_pix + p] = Cvt<T>::from_f(__fsub_rn(__fdiv_rn((float)frames[p * 3 + c], 127.5f), 1.0f));
+  }
+}
+
+int ttvk_clip_from_u8(const void* frames, long long n_pix, void* clip, int dtype, hipStream_t s) {
+  if (n_pix == 0) return TTV_OK;
+  TTV_CHECK_ARG((uintptr_t)frames % 4 == 0 && (uintptr_t)clip % 16 == 0 && n_pix % 4 == 0, "clip_from_u8: frames 4-byte, clip 16-byte aligned, T*H*W %% 4 == 0");
+  const long long groups = (n_pix + 3) / 4;
+  dim3 grid((unsigned)((groups + 255) / 256));
+  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_clip_from_u8<bf16_t>), grid, dim3(256), 0, s, (const uint8_t*)frames, (bf16_t*)clip, n_pix);
+  else if (dtype == TTV_F32) hipLaunchKernelGGL((k_clip_from_u8<float>), grid, dim3(256), 0, s, (const uint8_t*)frames, (float*)clip, n_pix);
+  else { ttv_set_error("clip_from_u8: bad dtype"); return TTV_ERR_INVALID; }
+  TTV_CHECK_LAUNCH("clip_from_u8");
+  return TTV_OK;
+}

@@ -25,6 +25,8 @@ int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t
 int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
                         int d, hipStream_t s);
 
+int ttvk_clip_from_u8(const void* frames, long long n_pix, void* clip, int dtype, hipStream_t s);
+
 // ---- ttv_gemm.hip ----
 // out^T-oriented GEMM: the MFMA "row" side is the output feature (W rows), the "column" side the token (X rows),
 // so every lane owns 4 consecutive output features of one token and the epilogues below are lane-local.

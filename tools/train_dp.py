@@ -10,7 +10,7 @@ them under the reference's token budget (train_seq_len 6144, token_range [1, 128
 of the reference's generator + discriminator step (train.py:64-107; L1 + relativistic GAN term, LPIPS off: no network) with the
 gradient all-reduce overlapped with the backward (titok_video_amd.dp.GradReducer) and the codebook-usage histogram all-reduced at the
 end.  The epoch ends collectively when the first rank runs out of batches.  Rank 0 prints ONE JSON line in bench.py's shape.
---check: world-size-1 runs repeat the first step with overlap off and report the largest parameter difference (expected 0)."""
+`python tools/train_dp.py --gpus N` without a launcher starts its own N ranks (as bench.py does) before touching the GPU."""
 import argparse
 import json
 import os
@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="without a launcher (WORLD_SIZE unset): start this many ranks, one per GPU")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shards", default="")
@@ -34,9 +35,25 @@ def main():
     ap.add_argument("--clips-per-shard", type=int, default=64)
     ap.add_argument("--seq-len", type=int, default=6144)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--workers", type=int, default=2, help="loader worker processes per rank (the reference uses 3, video_dataset.py:211)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # own fan-out, before anything touches the GPU (reference: L.Trainer(devices=N), train.py:270-280)
+        import socket
+        import subprocess
+        if args.backend != "gloo" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"train_dp.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (--backend gloo rehearses all ranks on cuda:0)")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                  env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                                           MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(args.gpus)]
+        codes = [p.wait() for p in procs]
+        if any(codes):
+            raise SystemExit(f"train_dp.py --gpus {args.gpus}: rank exit codes {codes}")
+        return
 
     import torch.distributed as dist
     from titok_video_amd import dp
@@ -44,7 +61,8 @@ def main():
     from titok_video_amd.data import dynamic_batches, equal_steps
     from titok_video_amd.model.losses import ReconstructionLoss
     from titok_video_amd.model.titok import TiTok
-    from titok_video_amd.shards import shard_samples, write_synthetic_shards
+    from titok_video_amd.loader import ShardBatchLoader
+    from titok_video_amd.shards import write_synthetic_shards
     from titok_video_amd.synthetic import seeded_titok_state, seeded_tower_state
     from titok_video_amd.train import freeze_python_gc, gan_training_step, make_discriminator_optimizer, make_optimizer
 
@@ -53,6 +71,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = args.backend == "gloo"                    # CPU-side collective, every rank on cuda:0 (one-GPU boxes)
     dev_index = 0 if rehearsal else local_rank
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    # ---- shards (rank 0 writes, everybody reads its own) and the loader's worker processes: BEFORE this process touches the GPU
+    # (the workers are forked; the ranks meet on a marker file, not on a collective)
+    shard_dir = args.shards or os.path.join(tempfile.gettempdir(), "ttv_shards_%s" % os.environ.get("MASTER_PORT", "single"))
+    n_shards = args.n_shards or 2 * world
+    marker = os.path.join(shard_dir, ".written")
+    if not args.shards:
+        if rank == 0:
+            write_synthetic_shards(shard_dir, n_shards, args.clips_per_shard, seed=11)
+            open(marker, "w").close()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(marker):
+                if time.time() - t_wait > 600:
+                    raise SystemExit("train_dp.py: rank 0 never finished writing the shards")
+                time.sleep(0.05)
+    paths = sorted(os.path.join(shard_dir, f) for f in os.listdir(shard_dir) if f.endswith(".tar"))[:n_shards]
+    loader = ShardBatchLoader(paths, rank, world, patch=(4, 8, 8), token_range=(1, 128), seq_len=args.seq_len, seed=100 + rank,
+                              workers=args.workers, epochs=None, drop_last=True).start()
+
+    if not rehearsal and torch.cuda.device_count() <= dev_index:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
@@ -61,16 +102,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-
-    # ---- shards (rank 0 writes, everybody reads its own)
-    shard_dir = args.shards or os.path.join(tempfile.gettempdir(), "ttv_shards")
-    n_shards = args.n_shards or 2 * world
-    if not args.shards and rank == 0:
-        write_synthetic_shards(shard_dir, n_shards, args.clips_per_shard, seed=11)
-    if world > 1:
-        dist.barrier()
-    paths = sorted(os.path.join(shard_dir, f) for f in os.listdir(shard_dir) if f.endswith(".tar"))[:n_shards]
 
     # ---- model, loss module (discriminator), optimisers: configs/tiny.yaml
     levels = [7, 5, 5, 5, 5]
@@ -91,8 +122,6 @@ def main():
     opt_d = make_discriminator_optimizer(loss_module) if loss_module is not None else None
     logger = CodebookLogger(4375, world_size=world)
 
-    samples = shard_samples(paths, rank=rank, world_size=world, dtype=dtype, device=device, epochs=None)
-    raw_batches = dynamic_batches(samples, (4, 8, 8), (1, 128), args.seq_len, seed=100 + rank, drop_last=True)
     freeze_python_gc()
 
     def one_step(batch):
@@ -106,28 +135,8 @@ def main():
         logger(torch.split(idx, counts))
         return len(clips), loss
 
-    # the stand-in for the reference's loader workers (3 processes, video_dataset.py:211): batches are decoded / uploaded by a
-    # background thread a few steps ahead, so the timed region measures the training step, not tar extraction
-    import queue
-    import threading
-    q = queue.Queue(maxsize=4)
-
-    def producer():
-        up = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(up):
-            for smp in raw_batches:          # uploads + normalisation run on this thread's own stream
-                up.synchronize()
-                q.put(smp)
-        q.put(None)
-    threading.Thread(target=producer, daemon=True).start()
-
-    def fetched():
-        while True:
-            b = q.get()
-            if b is None:
-                return
-            yield b
-    it = iter(equal_steps(fetched()))
+    # loader: worker processes decode + batch, one thread uploads and normalises on the GPU a few batches ahead (titok_video_amd/loader.py)
+    it = iter(equal_steps(loader.batches(device, dtype)))
     for _ in range(args.warmup):
         one_step(next(it))
     if world > 1:
@@ -164,6 +173,7 @@ def main():
                            "allreduce_slices_last_backward": int(red.slices) if red is not None else 0},
                 "loss_after_steps": float(loss), "codebook": scores}
         print(json.dumps(line), flush=True)
+    loader.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
