@@ -569,3 +569,20 @@ def test_psnr_matches_the_reference_definition(dtype):
     m.reset()
     m.update([target[0].to(DEV)], [target[0].to(DEV)])
     assert m.compute()["eval/psnr"] == float("inf")
+
+
+# ---------------------------------------------------------------------------------------------- loader tail
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(4, 16, 16), (8, 24, 40), (16, 168, 168)])
+def test_clip_from_u8_equals_the_host_normalisation(dt, shape):
+    """ttv_clip_from_u8 (uint8 [T,H,W,3] -> [3,T,H,W], u8 / 127.5 - 1, reference video_dataset.py:116-119) bit-equal to the torch
+    expression the host-side reader evaluates (shards.shard_samples), every byte value, both dtypes."""
+    t, h, w = shape
+    g = torch.Generator().manual_seed(t * h)
+    frames = torch.randint(0, 256, (t, h, w, 3), generator=g, dtype=torch.uint8)
+    frames.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
+    ref = (frames.permute(3, 0, 1, 2).to(torch.float32) / 127.5 - 1.0).to(DT[dt]).contiguous()
+    d8 = frames.to(DEV)
+    out = torch.empty((3, t, h, w), dtype=DT[dt], device=DEV)
+    _lib.check(L().ttv_clip_from_u8(d8.data_ptr(), t, h, w, out.data_ptr(), _lib.dtype_code(DT[dt]), S()), "clip_from_u8")
+    assert torch.equal(out.cpu(), ref)

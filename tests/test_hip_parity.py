@@ -311,9 +311,15 @@ def test_other_model_sizes_match_oracle(size, dtype):
         assert torch.equal(dd["indices"].cpu(), ref_idx)
         assert berr < 2e-3 and perr < 5e-3 * max(1.0, scale)
     else:
-        with torch.no_grad():    # yardstick: the oracle executed in bf16 on the same inputs
-            _r, y_idx, _z, y_b = O.titok_forward([c.to(torch.bfloat16) for c in clips_cpu], counts, sd, LEVELS, size, size)
-        assert_bf16_not_worse_than_yardstick(size, dd["indices"].cpu().numpy(), m.last_bounded.cpu(), ref_idx.numpy(), ref_b, y_idx.numpy(), y_b)
+        # yardstick: the REFERENCE's own modules run in bf16 on these inputs (tests/golden/titok_sizes.npz, make_golden_sizes.py).
+        # Round 2 used the CPU oracle evaluated in bf16 here; that is a more accurate bf16 execution than the reference's (mean error
+        # 0.0098 / 0.0170 against the reference's own 0.0143 / 0.0246 for small / base), i.e. a bar the reference does not meet.
+        g = np.load(os.path.join(G, "titok_sizes.npz"))
+        assert g["shapes"].tolist() == [list(s_) for s_ in shapes] and g["counts"].tolist() == counts and int(g["clip_seed"]) == 13
+        assert np.array_equal(ref_idx.numpy(), g[f"{size}_indices"])                 # the oracle's fp32 run IS the reference's
+        assert_bf16_not_worse_than_yardstick(size, dd["indices"].cpu().numpy(), m.last_bounded.cpu(), g[f"{size}_indices"],
+                                             torch.from_numpy(g[f"{size}_bounded"]), g[f"{size}_indices_refbf16"],
+                                             torch.from_numpy(g[f"{size}_bounded_refbf16"]))
         assert perr < 0.08 * max(1.0, scale)
 
 
@@ -377,9 +383,9 @@ def test_sampling_range_extremes_fp32_match_oracle():
     sd = seeded_titok_state(0)
     ref_recon, ref_idx, _ref_z, ref_bounded = O.titok_forward([c.cpu() for c in clips], counts, sd, LEVELS)
     idx = od["indices"].cpu()
-    assert idx.shape == (130,)
+    assert idx.shape == (386,)
     safe = O.fsq_margin(ref_bounded) > TAU_F32
-    assert int(safe.sum()) >= 120
+    assert int(safe.sum()) >= 360
     assert torch.equal(idx[safe], ref_idx[safe])
     np.testing.assert_allclose(model.last_bounded.cpu().numpy(), ref_bounded.numpy(), rtol=0, atol=2e-3)
     for r, ref in zip(recon, ref_recon):

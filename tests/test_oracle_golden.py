@@ -192,3 +192,19 @@ def test_loss_oracle_gradients_follow_the_reference_bf16_run():
         got = sdg[n].grad.double().flatten()
         cos = float(torch.dot(ref, got) / (ref.norm() * got.norm()))
         assert cos > 0.9, (n, cos)
+
+
+@pytest.mark.parametrize("size", ["small", "base", "large"])
+def test_oracle_other_sizes_equal_the_reference(size):
+    """tests/golden/titok_sizes.npz (reference modules, fp32 and bf16, make_golden_sizes.py): the oracle's fp32 encoder + FSQ gives the
+    reference's indices on all 384 tokens and its pre-rounding values to 2e-5 for get_model_dims small / base / large."""
+    from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
+    g = np.load(os.path.join(G, "titok_sizes.npz"))
+    sd = seeded_titok_state(int(g["weight_seed"]), encoder_size=size, decoder_size=size, gain=float(g["weight_gain"]))
+    clips = synthetic_clips(g["shapes"].tolist(), seed=int(g["clip_seed"]))
+    with torch.no_grad():
+        _r, idx, _z, b = O.titok_forward(clips, g["counts"].tolist(), sd, g["levels"].tolist(), size, size)
+    assert np.array_equal(idx.numpy(), g[f"{size}_indices"])
+    assert float(np.abs(b.numpy() - g[f"{size}_bounded"]).max()) < 2e-5
+    # and the reference's own bf16 run is the yardstick the GPU tests use: it differs from its fp32 run
+    assert int((g[f"{size}_indices_refbf16"] != g[f"{size}_indices"]).sum()) > 0

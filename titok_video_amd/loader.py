@@ -5,11 +5,14 @@ decode -> `_video_process` -> `_dynamic_batching`).  Round 2's stand-in decoded,
 thread of the training process and was the whole step: 45 ms per step against 3.5 ms of GPU work.  Here
 
   * WORKER PROCESSES (forked before the training process touches the GPU) read this rank's shards, keep the frames as the decoder
-    hands them over - uint8 [T,H,W,3] - and run the reference's token-budget batching (data.dynamic_batches) on them; a batch
-    crosses to the training process as shared-memory tensors (no pickling of pixel data);
-  * one thread of the training process copies a batch into PINNED staging memory, uploads the uint8 frames (a quarter of the bytes
-    of fp32 clips) on its own stream and normalises them ON THE GPU in one launch per clip (ttv_clip_from_u8: u8 / 127.5 - 1,
-    dataset/video_dataset.py:116-119), records an event and hands the batch over;
+    hands them over - uint8 [T,H,W,3] - and run the reference's token-budget batching (data.dynamic_batches) on them.  A batch's
+    frames are written into one slot of a ring of shared-memory buffers allocated ONCE before the fork; only the slot number and
+    the clip shapes cross the queue.  (Fresh shared-memory tensors per batch cost the consumer 20-30 ms per batch in first-touch
+    page faults of the new mappings - measured, tools/loader_bench.py.)
+  * the training process registers those rings as PINNED host memory (hipHostRegister) after its first GPU call; one thread uploads
+    a batch's uint8 frames straight from the ring (a quarter of the bytes of fp32 clips, no staging copy) on its own stream and
+    normalises them ON THE GPU in one launch per clip (ttv_clip_from_u8: u8 / 127.5 - 1, dataset/video_dataset.py:116-119),
+    records an event, hands the batch over and returns the slot to its worker once the event has completed;
   * the consumer makes the compute stream wait for that event and calls `record_stream` on every clip, so the allocator cannot hand
     a clip's memory back to the upload stream while the training step is still reading it.
 
@@ -53,15 +56,22 @@ def raw_shard_samples(paths: Sequence[str], epochs: Optional[int] = 1) -> Iterat
         ep += 1
 
 
-def _worker_main(paths, patch, token_range, seq_len, seed, epochs, drop_last, out_q, release):
+def _worker_main(paths, patch, token_range, seq_len, seed, epochs, drop_last, ring, free_q, out_q, release):
     torch.set_num_threads(1)
     try:
         for b in dynamic_batches(raw_shard_samples(paths, epochs), patch, token_range, seq_len, seed=seed, drop_last=drop_last):
-            frames = [v.permute(1, 2, 3, 0).contiguous().share_memory_() for v in b["video"]]      # back to [T,H,W,3], in shared memory
-            out_q.put({"frames": frames, "fps": b["fps"], "__key__": b["__key__"], "token_counts": b["token_counts"].tolist()})
+            slot = free_q.get()                    # flow control: a slot the consumer has finished uploading from
+            buf, off, clips = ring[slot], 0, []
+            for v in b["video"]:                   # channel-first view of [T,H,W,3] frames: write them back as the decoder's layout
+                t, h, w = v.shape[1:]
+                n = 3 * t * h * w
+                buf[off:off + n].view(t, h, w, 3).copy_(v.permute(1, 2, 3, 0))
+                clips.append((off, t, h, w))
+                off += (n + 15) // 16 * 16
+            out_q.put({"slot": slot, "clips": clips, "fps": b["fps"], "__key__": b["__key__"], "token_counts": b["token_counts"].tolist()})
     finally:
         out_q.put(None)
-        release.wait()          # shared-memory tensors are handed over by file descriptor: stay alive until the consumer is done
+        release.wait()
 
 
 class ShardBatchLoader:
@@ -77,8 +87,11 @@ class ShardBatchLoader:
         self.workers = max(1, min(workers, len(mine)))
         self._args = [([p for j, p in enumerate(mine) if j % self.workers == w], tuple(patch), tuple(token_range), seq_len, seed + 1009 * w,
                        epochs, drop_last) for w in range(self.workers)]
-        self.prefetch = prefetch
-        self._procs, self._queues = [], []
+        self.prefetch = max(2, prefetch)
+        # a batch holds at most seq_len patch rows of prod(patch) * 3 bytes each (+ 16-byte alignment per clip)
+        self.slot_bytes = int(seq_len) * int(np.prod(patch)) * 3 + 4096
+        self._procs, self._queues, self._free, self._rings = [], [], [], []
+        self._registered = False
         self._stop = threading.Event()
 
     def start(self) -> "ShardBatchLoader":
@@ -87,15 +100,21 @@ class ShardBatchLoader:
         ctx = mp.get_context("fork")
         self._release = ctx.Event()
         for a in self._args:
-            q = ctx.Queue(maxsize=self.prefetch)
-            p = ctx.Process(target=_worker_main, args=(*a, q, self._release), daemon=True)
+            ring = torch.zeros(self.prefetch, self.slot_bytes, dtype=torch.uint8).share_memory_()     # mapped once, before the fork
+            q, fq = ctx.Queue(), ctx.Queue()
+            for i in range(self.prefetch):
+                fq.put(i)
+            p = ctx.Process(target=_worker_main, args=(*a, ring, fq, q, self._release), daemon=True)
             p.start()
             self._procs.append(p)
             self._queues.append(q)
+            self._free.append(fq)
+            self._rings.append(ring)
         return self
 
-    def raw_batches(self) -> Iterator[Dict]:
-        """The workers' batches in the fixed round-robin order (uint8 frames in shared memory); ends when every worker is done."""
+    def _raw(self) -> Iterator[Dict]:
+        """The workers' batch descriptors in the fixed round-robin order; `frames` are VIEWS into the worker's ring slot, valid until
+        `release(b)` hands the slot back."""
         live = list(range(self.workers))
         while live:
             for w in list(live):
@@ -103,7 +122,19 @@ class ShardBatchLoader:
                 if b is None:
                     live.remove(w)
                     continue
+                b["worker"] = w
+                b["frames"] = [self._rings[w][b["slot"]][off:off + 3 * t * h * wd].view(t, h, wd, 3) for off, t, h, wd in b["clips"]]
                 yield b
+
+    def release(self, b: Dict) -> None:
+        self._free[b["worker"]].put(b["slot"])
+
+    def raw_batches(self) -> Iterator[Dict]:
+        """Host-side batches (tests, CPU consumers): the frames are copied out of the ring and the slot is returned at once."""
+        for b in self._raw():
+            b["frames"] = [f.clone() for f in b["frames"]]
+            self.release(b)
+            yield b
 
     def batches(self, device, dtype=torch.bfloat16, depth: int = 3) -> Iterator[Dict]:
         """Device batches.  A thread stages / uploads / normalises `depth` batches ahead on its own stream; the generator makes the
@@ -116,39 +147,51 @@ class ShardBatchLoader:
         def uploader():
             torch.cuda.set_device(device)
             up = torch.cuda.Stream(device=device)
-            slots = [None] * (depth + 2)          # pinned staging buffers with the event of their last upload
-            k = 0
+            if not self._registered:               # the rings become pinned host memory: uploads go straight from them
+                rt = torch.cuda.cudart()
+                self._pinned = all(int(rt.cudaHostRegister(r.data_ptr(), r.numel(), 0)) == 0 for r in self._rings)
+                self._registered = True
+            staging = None
+            in_flight = []                         # (event, batch descriptor): slots whose upload may still be reading
             try:
-                for b in self.raw_batches():
+                for b in self._raw():
                     if self._stop.is_set():
                         break
-                    n_bytes = sum(f.numel() for f in b["frames"])
-                    slot = slots[k % len(slots)]
-                    if slot is not None and slot[1] is not None:
-                        slot[1].synchronize()      # the upload that last read this staging buffer has finished
-                    if slot is None or slot[0].numel() < n_bytes:
-                        slot = [torch.empty(max(n_bytes, 1 << 22), dtype=torch.uint8).pin_memory(), None]
-                    off, views = 0, []
-                    for f in b["frames"]:
-                        v = slot[0][off:off + f.numel()].view(f.shape)
-                        v.copy_(f)                 # shared memory -> pinned (a memcpy: releases the GIL)
-                        views.append(v)
-                        off += (f.numel() + 15) // 16 * 16
+                    while in_flight and (in_flight[0][0].query() or len(in_flight) >= self.prefetch - 1):
+                        ev0, b0 = in_flight.pop(0)
+                        ev0.synchronize()
+                        self.release(b0)
+                    frames = b["frames"]
+                    if not self._pinned:           # registration refused: one staging copy through ordinary pinned memory
+                        n_bytes = sum(f.numel() for f in frames)
+                        if staging is None or staging.numel() < n_bytes:
+                            staging = torch.empty(max(n_bytes, self.slot_bytes), dtype=torch.uint8).pin_memory()
+                        off, views = 0, []
+                        for f in frames:
+                            v = staging[off:off + f.numel()].view(f.shape)
+                            v.copy_(f)
+                            views.append(v)
+                            off += (f.numel() + 15) // 16 * 16
+                        frames = views
                     with torch.cuda.stream(up):
                         clips = []
-                        for v in views:
+                        for v in frames:
                             t, h, w, _c = v.shape
-                            d8 = v.to(device, non_blocking=True)
+                            d8 = torch.empty(v.shape, dtype=torch.uint8, device=device)
+                            d8.copy_(v, non_blocking=True)
                             clip = torch.empty((3, t, h, w), dtype=dtype, device=device)
                             _lib.check(lib.ttv_clip_from_u8(d8.data_ptr(), t, h, w, clip.data_ptr(), code, up.cuda_stream), "ttv_clip_from_u8")
                             clips.append(clip)
                         ev = torch.cuda.Event()
                         ev.record(up)
-                    slot[1] = ev
-                    slots[k % len(slots)] = slot
-                    k += 1
+                    if not self._pinned:
+                        ev.synchronize()           # the staging buffer is reused by the next batch
+                    in_flight.append((ev, b))
                     out_q.put(({"video": clips, "fps": b["fps"], "__key__": b["__key__"],
                                 "token_counts": torch.tensor(b["token_counts"], dtype=torch.int32)}, ev))
+                for ev0, b0 in in_flight:
+                    ev0.synchronize()
+                    self.release(b0)
             finally:
                 out_q.put(None)
 
@@ -176,4 +219,8 @@ class ShardBatchLoader:
                 p.terminate()
         for p in self._procs:
             p.join(timeout=5)
-        self._procs, self._queues = [], []
+        if self._registered and getattr(self, "_pinned", False):
+            rt = torch.cuda.cudart()
+            for r in self._rings:
+                rt.cudaHostUnregister(r.data_ptr())
+        self._procs, self._queues, self._free, self._rings, self._registered = [], [], [], [], False
