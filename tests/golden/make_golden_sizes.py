@@ -52,6 +52,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "titok_sizes.npz"), **out)
     print("wrote titok_sizes.npz", os.path.getsize(os.path.join(HERE, "titok_sizes.npz")) // 1024, "KiB")
 
+    # the corners of the loader's sampling ranges (configs/tiny.yaml:57-62) through the tiny model: largest grid with K = 128 and K = 1,
+    # smallest grid with K = 1, two small full-K clips - 386 tokens; yardstick of test_sampling_range_extremes_bf16_close_to_oracle
+    shapes, counts, seed = [(16, 168, 168), (8, 128, 128), (16, 168, 168), (4, 16, 16), (8, 16, 24)], [128, 1, 1, 128, 128], 77
+    ex = {"shapes": np.array(shapes, dtype=np.int32), "counts": np.array(counts, dtype=np.int32), "clip_seed": np.int32(seed),
+          "weight_seed": np.int32(0), "levels": np.array(LEVELS, dtype=np.int32)}
+    cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=LEVELS, encoder_size="tiny", decoder_size="tiny")))
+    sd = seeded_titok_state(0)
+    for dtype, tag in ((torch.float32, ""), (torch.bfloat16, "_refbf16")):
+        model = TiTok(cfg).eval()
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dtype)
+        clips = [c.to(dtype) for c in synthetic_clips(shapes, seed=seed)]      # as the GPU test: fp32 clips rounded to the run's dtype
+        tc = torch.tensor(counts, dtype=torch.int32)
+        grids = torch.tensor(shapes, dtype=torch.int32)
+        with torch.no_grad():
+            z = model.encoder(clips, tc, grids)
+            _codes, d = model.quantize(z)
+            bounded = model.quantize.bound(z.float())
+        ex["indices" + tag] = d["indices"].numpy().astype(np.int32)
+        ex["bounded" + tag] = bounded.float().numpy()
+    e = np.abs(ex["bounded_refbf16"] - ex["bounded"])
+    print(f"extremes: reference bf16 vs fp32: mean |bounded err| {e.mean():.5f}, max {e.max():.4f}, mismatches {int((ex['indices_refbf16'] != ex['indices']).sum())}/386")
+    np.savez_compressed(os.path.join(HERE, "titok_extremes.npz"), **ex)
+    print("wrote titok_extremes.npz")
+
 
 if __name__ == "__main__":
     main()

@@ -398,7 +398,8 @@ def test_sampling_range_extremes_fp32_match_oracle():
 
 def test_sampling_range_extremes_bf16_close_to_oracle():
     """Same corners through the bf16 kernels (fused tail, gathered proj_in, scattered proj_out, LDS-DMA attention with an odd
-    number of key tiles): not worse than a bf16 execution of the oracle on the same inputs (fixed thresholds, see the header)."""
+    number of key tiles): not worse than the REFERENCE's own bf16 run on the same inputs (tests/golden/titok_extremes.npz,
+    make_golden_sizes.py; fixed thresholds, see the header)."""
     # the extremes of the loader's ranges (largest grid with K = 128 and with K = 1) plus two full-K clips: 386 tokens
     shapes, counts = [(16, 168, 168), (8, 128, 128), (16, 168, 168), (4, 16, 16), (8, 16, 24)], [128, 1, 1, 128, 128]
     clips32 = synthetic_clips(shapes, seed=77, dtype=torch.float32, device="cpu")
@@ -408,11 +409,10 @@ def test_sampling_range_extremes_bf16_close_to_oracle():
         codes, od = model.encode(clips, counts, want_bounded=True)
         recon = model.decode(codes, counts, shapes)
     sd = seeded_titok_state(0)
-    with torch.no_grad():
-        _r, ref_idx, _z, ref_bounded = O.titok_forward([c.to(torch.bfloat16).float() for c in clips32], counts, sd, LEVELS)
-        _r, y_idx, _z, y_b = O.titok_forward([c.to(torch.bfloat16) for c in clips32], counts, sd, LEVELS)    # yardstick: the oracle in bf16
-    assert_bf16_not_worse_than_yardstick("sampling corners", od["indices"].cpu().numpy(), model.last_bounded.cpu(), ref_idx.numpy(),
-                                         ref_bounded, y_idx.numpy(), y_b)
+    g = np.load(os.path.join(G, "titok_extremes.npz"))
+    assert g["shapes"].tolist() == [list(s_) for s_ in shapes] and g["counts"].tolist() == counts and int(g["clip_seed"]) == 77
+    assert_bf16_not_worse_than_yardstick("sampling corners", od["indices"].cpu().numpy(), model.last_bounded.cpu(), g["indices"],
+                                         torch.from_numpy(g["bounded"]), g["indices_refbf16"], torch.from_numpy(g["bounded_refbf16"]))
     dec_ref = O.titok_decode_indices(od["indices"].cpu(), shapes, counts, sd, LEVELS)
     for r, ref in zip(recon, dec_ref):
         assert float((r.float().cpu() - ref).abs().max()) < PIX_TOL_BF16 * 1.5

@@ -208,3 +208,16 @@ def test_oracle_other_sizes_equal_the_reference(size):
     assert float(np.abs(b.numpy() - g[f"{size}_bounded"]).max()) < 2e-5
     # and the reference's own bf16 run is the yardstick the GPU tests use: it differs from its fp32 run
     assert int((g[f"{size}_indices_refbf16"] != g[f"{size}_indices"]).sum()) > 0
+
+
+def test_oracle_sampling_extremes_equal_the_reference():
+    """tests/golden/titok_extremes.npz: the corners of the loader's sampling ranges (largest grid with K = 128 and K = 1) through the
+    reference's tiny model - the oracle reproduces its fp32 indices (386 tokens)."""
+    from titok_video_amd.synthetic import seeded_titok_state, synthetic_clips
+    g = np.load(os.path.join(G, "titok_extremes.npz"))
+    sd = seeded_titok_state(int(g["weight_seed"]))
+    clips = synthetic_clips(g["shapes"].tolist(), seed=int(g["clip_seed"]))
+    with torch.no_grad():
+        _r, idx, _z, b = O.titok_forward(clips, g["counts"].tolist(), sd, g["levels"].tolist())
+    assert np.array_equal(idx.numpy(), g["indices"])
+    assert float(np.abs(b.numpy() - g["bounded"]).max()) < 2e-5
