@@ -47,6 +47,7 @@ static inline int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
 struct TowerWs {
   char *x, *xn, *qkv, *ao, *h, *pa, *pb;
   float* y32;
+  float* rstd;     // [L] row statistic of a folded pre-norm (generic-width bf16 towers)
   int64_t total;
 };
 
@@ -66,6 +67,7 @@ static TowerWs carve(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
   w.h = take(L * d->inner * e);
   w.pa = take(P * pd * e);        // encoder: gathered patches; decoder: proj_out output
   w.pb = take(P * d->width * e);  // encoder: proj_in output;   decoder: ln_post output
+  w.rstd = (float*)take(L * 4);
   w.total = off;
   return w;
 }
@@ -87,6 +89,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
   const int nq = 2 * dm + 2 * g;
   bool qkv_ready = false;   // the previous layer's tail kernel already produced this layer's rotated qkv
+  bool rstd_valid = false;  // ws.rstd holds rsqrt(mean(x^2) + eps) of the current ws.x (written by the kernel that produced x)
   static const bool attn_pipe = getenv("TTV_ATTN_PIPE") && getenv("TTV_ATTN_PIPE")[0] == '1';   // opt-in pipelined attention kernel
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
@@ -104,17 +107,24 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_gemm_fp8(EPI_QKV_ROPE, a, f8_scales, lw.to_qkv_f8_scale, s));
     } else if (!qkv_ready) {
       const bool fold_qkv = dt == TTV_BF16 && dm == 256 && lw.to_qkv_pn;
-      if (!fold_qkv) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+      // other widths: the gain is folded into the weight as well (to_qkv_pn), the row statistic comes from the kernel that
+      // produced x (the KEEL post-norm below writes it) or from one light pass, and multiplies the GEMM's output rows - no
+      // stand-alone RMSNorm launch, no normalised copy of x
+      const bool fold_gen = dt == TTV_BF16 && dm != 256 && lw.to_qkv_pn;
+      if (fold_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
+      if (!fold_qkv && !fold_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
       GemmArgs a = {};
       a.dtype = dt;
       a.prenorm = fold_qkv; a.eps = d->eps;
+      a.row_scale = fold_gen ? ws.rstd : nullptr;
       const void* w_plain = (dt == TTV_BF16 && lw.to_qkv_qs) ? lw.to_qkv_qs : lw.to_qkv;   // inference copy with scaled q rows, if packed
-      a.x = fold_qkv ? ws.x : ws.xn; a.ldx = dm; a.w = fold_qkv ? lw.to_qkv_pn : w_plain; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+      a.x = (fold_qkv || fold_gen) ? ws.x : ws.xn; a.ldx = dm; a.w = (fold_qkv || fold_gen) ? lw.to_qkv_pn : w_plain; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
       a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
       TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     }
     // q arrives pre-scaled when the projection used the folded weight whose q rows carry scale * log2(e)
-    const bool q_scaled = dt == TTV_BF16 && ((dm == 256 && lw.to_qkv_pn) ? lw.qkv_q_prescaled != 0 : lw.to_qkv_qs != nullptr);
+    const bool q_scaled = dt == TTV_BF16 && (lw.to_qkv_pn ? lw.qkv_q_prescaled != 0 : lw.to_qkv_qs != nullptr);
+    rstd_valid = false;
     qkv_ready = false;
     if (q_scaled && b->items64 && b->n_items64 > 0 && d->head_dim == 64)
       TTV_TRY(ttvk_attention64(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->items64, b->n_items64, d->q_heads, d->kv_heads,
@@ -154,23 +164,29 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     } else {
       o.alpha = d->alpha; o.y = ws.y32; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
-      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
+      const bool want = dt == TTV_BF16 && dm != 256 && lw.w12_pn && !f8_w12;
+      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      rstd_valid = want;
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
     const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
+    const bool fold_ffd_gen = dt == TTV_BF16 && dm != 256 && lw.w12_pn && !f8_w12;
     if (f8_w12) {
       TTV_TRY(ttvk_quant_rows_fp8(ws.x, dt, dm, lw.ffd_norm, d->eps, ws.xn, dm, f8_scales, L, dm, s));
       GemmArgs f = {};
       f.dtype = dt; f.x = ws.xn; f.ldx = dm; f.w = lw.w12_f8; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
       TTV_TRY(ttvk_gemm_fp8(EPI_GEGLU, f, f8_scales, lw.w12_f8_scale, s));
     } else {
-    if (!fold_ffd) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+    if (fold_ffd_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
+    if (!fold_ffd && !fold_ffd_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
     f.dtype = dt;
     f.prenorm = fold_ffd; f.eps = d->eps;
-    f.x = fold_ffd ? ws.x : ws.xn; f.ldx = dm; f.w = fold_ffd ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
+    f.row_scale = fold_ffd_gen ? ws.rstd : nullptr;
+    f.x = (fold_ffd || fold_ffd_gen) ? ws.x : ws.xn; f.ldx = dm; f.w = (fold_ffd || fold_ffd_gen) ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
     TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
     }
+    rstd_valid = false;
     GemmArgs f3 = {};
     f3.dtype = dt;
     f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = L; f3.N = dm; f3.K = d->inner; f3.resid = ws.x; f3.ldr = dm;
@@ -184,7 +200,9 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     } else {
       f3.alpha = d->alpha; f3.y = ws.y32; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
-      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s));
+      const bool want = dt == TTV_BF16 && dm != 256 && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn && !(w->layers[i + 1].to_qkv_f8 && w->layers[i + 1].to_qkv_f8_scale);
+      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      rstd_valid = want;
     }
   }
   return TTV_OK;

@@ -14,7 +14,8 @@
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int ld_in, const int* __restrict__ src_rows,
                                                  TO* __restrict__ out, int ld_out, const int* __restrict__ dst_rows,
-                                                 const float* __restrict__ gain, int rows, int d, float eps) {
+                                                 const float* __restrict__ gain, int rows, int d, float eps,
+                                                 float* __restrict__ next_rstd) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
   if (r >= rows) return;
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int 
   const TI* p = in + (size_t)sr * ld_in;
   f32x4 v[MAX_ITERS];
   float ss = 0.f;
+  float so = 0.f;       // next_rstd: sum of squares of the row as STORED (rounded to TO) - what the next pre-norm will read
 #pragma unroll
   for (int it = 0; it < MAX_ITERS; ++it) {
     const int c = (it * 64 + lane) * 4;
@@ -41,29 +43,68 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int 
       const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
       f32x4 o = {v[it][0] * rstd * g[0], v[it][1] * rstd * g[1], v[it][2] * rstd * g[2], v[it][3] * rstd * g[3]};
       Vec4<TO>::store(q + c, o);
+      if (next_rstd) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float w = round_to<TO>(o[e]); so = fmaf(w, w, so); }
+      }
     }
   }
+  if (next_rstd) {       // wave-uniform
+    so = wave_sum(so);
+    if (lane == 0) next_rstd[dr] = 1.0f / sqrtf(so / (float)d + eps);
+  }
+}
+
+// rstd[r] = rsqrt(mean(x_r^2) + eps): the row statistic of an RMSNorm whose gain is folded into the next linear's weight and
+// whose scale is applied to that GEMM's output rows (generic-width towers; the width-256 GEMM takes it from the register-resident row)
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_rstd(const T* __restrict__ in, int ld_in, float* __restrict__ rstd, int rows, int d, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  const T* p = in + (size_t)r * ld_in;
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAX_ITERS; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < d) {
+      const f32x4 v = Vec4<T>::load(p + c);
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) rstd[r] = 1.0f / sqrtf(ss / (float)d + eps);
+}
+
+int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, int d, float eps, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS && ld_in % 4 == 0, "row_rstd: width / leading dim");
+  dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
+  if (dtype == TTV_BF16) hipLaunchKernelGGL((k_row_rstd<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, ld_in, rstd, rows, d, eps);
+  else hipLaunchKernelGGL((k_row_rstd<float>), grid, dim3(256), 0, s, (const float*)in, ld_in, rstd, rows, d, eps);
+  TTV_CHECK_LAUNCH("row_rstd");
+  return TTV_OK;
 }
 
 template <typename TI, typename TO>
 static int launch_rmsnorm(const void* in, int ld_in, const int* src_rows, void* out, int ld_out, const int* dst_rows,
-                          const float* gain, int rows, int d, float eps, hipStream_t s) {
+                          const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd) {
   if (rows == 0) return TTV_OK;
   TtvProfScope prof(TTV_KC_RMSNORM, s);
   hipLaunchKernelGGL((k_rmsnorm<TI, TO>), dim3(ttv_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, s, (const TI*)in, ld_in,
-                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps);
+                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps, next_rstd);
   TTV_CHECK_LAUNCH("rmsnorm");
   return TTV_OK;
 }
 
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
-                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s) {
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd) {
   TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS, "rmsnorm: width %d must be a multiple of 4 and <= 1024", d);
   TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "rmsnorm: leading dims must be multiples of 4");
-  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
-  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
-  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
-  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s);
+  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
+  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
   ttv_set_error("rmsnorm: bad dtypes %d %d", in_dtype, out_dtype);
   return TTV_ERR_INVALID;
 }

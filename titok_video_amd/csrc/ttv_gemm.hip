@@ -40,6 +40,7 @@ struct GemmDev {
   ClipPtrs clips;
   const int* clip_desc; const int* patch_rows; const int* row_seq;
   const int* x_rows;   // k256: GEMM row t reads x row x_rows[t] (NULL = identity)
+  const float* row_scale;   // optional [M]: acc rows are multiplied by it first (folded pre-norm of the generic-K kernels)
   const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma)
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
 };
@@ -79,6 +80,18 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
   for (int j = 0; j < NJ; ++j) { tv[j] = tok[j] < p.M; tc[j] = tv[j] ? tok[j] : p.M - 1; }
 #pragma unroll
   for (int i = 0; i < NI; ++i) { fv[i] = feat[i] < p.N; fc[i] = fv[i] ? feat[i] : p.N - 4; }
+
+  if (p.row_scale) {     // folded pre-norm: y = rstd[token] * (x (W o gain)^T); uniform branch
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float rs = p.row_scale[tc[j]];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i][j] *= rs;
+        if (EPI == EPI_GEGLU) acc2[i][j] *= rs;
+      }
+    }
+  }
 
   if (EPI == EPI_STORE || EPI == EPI_STORE_PATCH) {
     if (p.bias) {
@@ -1353,6 +1366,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;
   d.x_rows = a.x_rows;
   d.x_scale = nullptr; d.w_scale = nullptr;
+  d.row_scale = a.row_scale;
+  TTV_CHECK_ARG(!a.row_scale || (a.dtype == TTV_BF16 && (epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU)), "gemm: row_scale is a bf16 STORE / QKV_ROPE / GEGLU option");
   TTV_CHECK_ARG(!a.x_rows || (a.dtype == TTV_BF16 && a.K == 256 && a.N % 8 == 0 && epi != EPI_RESID_NORM), "gemm: x_rows needs the bf16 K=256 kernel");
   if (epi == EPI_STORE_PATCH || a.gather) {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };

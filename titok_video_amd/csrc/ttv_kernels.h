@@ -7,7 +7,8 @@
 
 // ---- ttv_elem.hip ----
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
-                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s);
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd = nullptr);
+int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, int d, float eps, hipStream_t s);
 int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* mask_token,
                          const float* gain, float eps, hipStream_t s);
 int ttvk_dec_embed(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain,
@@ -55,6 +56,8 @@ struct GemmArgs {
   int dtype;
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
+  const float* row_scale;          // optional [M]: output row t is multiplied by row_scale[t] before the epilogue (the rstd of a pre-norm
+                                   // whose gain is folded into w: any K; bf16 kernels)
   const int* x_rows;               // optional (bf16, K == 256): GEMM row t reads x row x_rows[t]
   float eps;
   // EPI_STORE_PATCH (output side) / gather (EPI_STORE, input side): row t of the GEMM is patch t (clip-major); its clip is

@@ -318,16 +318,19 @@ class _WeightPack:
             return t.data_ptr()
 
         fold = dtype == torch.bfloat16 and tower.width == 256
+        # other widths: the pre-norm gains are folded into to_qkv / w12 as well; the generic GEMM then scales its output rows by the
+        # row statistic the producing kernel wrote (ttv_layer_weights.to_qkv_pn / w12_pn; TTV_FOLD_NORMS=0 keeps the stand-alone norms)
+        fold_gen = dtype == torch.bfloat16 and tower.width != 256 and os.environ.get("TTV_FOLD_NORMS", "1") != "0"
 
         # q rows of the folded QKV weight carry head_dim^-0.5 * log2(e): the projection then emits the softmax exponent and the
         # attention kernel saves a multiply-add per score (TTV_ATTN_QSCALED).  Applied in fp32 before the one rounding to bf16.
         use_qs = dtype == torch.bfloat16 and os.environ.get("TTV_ATTN_QSCALE", "1") != "0"
         q_scale = 0.125 * 1.4426950408889634 if use_qs else None
-        self.q_prescaled = 1 if (fold and use_qs) else 0
+        self.q_prescaled = 1 if ((fold or fold_gen) and use_qs) else 0
 
         def lin_qs(w):
             """Inference copy of to_qkv with the factor on its q rows, for towers whose QKV GEMM does not take the folded weight."""
-            if fold or not use_qs:
+            if fold or fold_gen or not use_qs:
                 return None
             t = w.detach().to(device=device, dtype=torch.float32).clone()
             t[:tower.width] *= q_scale
@@ -360,8 +363,8 @@ class _WeightPack:
             return t.to(dtype).contiguous()
 
         def folded(w, g, q_rows=0):
-            """w * gain[None, :] in fp32, then the compute dtype: lets the K=256 GEMM kernel absorb the pre-norm."""
-            if not fold:
+            """w * gain[None, :] in fp32, then the compute dtype: lets the GEMM absorb the pre-norm."""
+            if not (fold or fold_gen):
                 return None
             t = folded_tensor(w, g, q_rows)
             keep.append(t)
@@ -417,7 +420,7 @@ class _WeightPack:
             proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
             proj_out_w=lin(w_out), proj_out_b=lin(b_out), layers=self.layers,
-            proj_out_pn=folded(w_out, tower.ln_post.weight) if tower.kind == _lib.TTV_DECODER else None)
+            proj_out_pn=folded(w_out, tower.ln_post.weight) if (tower.kind == _lib.TTV_DECODER and fold) else None)
         self.keep = keep
         self.kind, self.n_layers = tower.kind, n
         self._t = None
