@@ -2,7 +2,7 @@
 // (replaces flash_attn_varlen_func at reference model/base/transformer.py:100 and the gate at :103).
 //
 // bf16 kernel (head_dim 64).  One workgroup = 4 waves = 128 query rows of one (sequence, q-head); each wave owns
-// 32 queries.  K/V tiles of 64 keys are staged by LDS-DMA into double-buffered, XOR-swizzled LDS (164 VGPRs with pre-scaled q and the gate: 3 blocks per CU).
+// 32 queries.  K/V tiles of 64 keys are staged by LDS-DMA into double-buffered, XOR-swizzled LDS (157 VGPRs with pre-scaled q and the gate, no AGPRs: 3 blocks per CU).
 // "Half items" (work-table mode 1): 64 query rows, wave pairs split the key range and merge their (O, m, l) at the end.
 //   S^T = K Q^T   : mfma_f32_32x32x16_bf16 with the KEY on the MFMA row and the QUERY on the lane (col = lane&31),
 //                   so a lane holds 32 scores of ONE query: row max / row sum are in-lane plus one xor-32 exchange.
@@ -67,10 +67,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 // when a tile raises the maximum (rare after the first tiles) the tile's scores, the running state and the start vector are shifted.
 // TAPE: the training forward - additionally writes the log-sum-exp per (row, head) and, with the gate, the ungated output.
 //
-// What bounds it (profiles/r02_attn_*): a wave needs ~2 000 cycles per 64-key tile on its own (in-kernel stamps: barrier + DMA wait
-// 15 %, DMA issue + K fragment reads + S MFMAs 28 %, S completion + row maximum 11 %, 32 exp2 + pack 25 %, V reads + PV MFMAs 21 %)
-// and ~2 900 with three waves per SIMD: the chain of dependent phases of ONE wave, not a saturated pipe (matrix pipe ~35-45 %
-// busy, vector issue ~35 %).  Everything off that chain that could be moved has been:
+// What bounds it: in-kernel stamps of this kernel are in profiles/r03_attn_stamps.txt (tools/attn_stamps.py; per wave and 64-key
+// tile at three waves per SIMD) - the figures round 2 quoted here had no committed source (its stamps file was empty for this
+// kernel).  Per SIMD the kernel spends ~3 800 cycles per 64 query rows x 64 keys against 1 024 cycles of MFMA; the round-3 study
+// of a 64-rows-per-wave structure (ttv_attn64.hip) shows the loop CAN run at ~2 100, and what then remains.
+// Everything off the wave's chain of dependent phases that could be moved has been:
 //   * the running reference of the softmax moves only when a score exceeds it by more than `defer_thr` (see below);
 //   * the DMA source of a tile is a scalar base (advanced per tile on the scalar unit) plus lane-constant offsets: no per-tile
 //     address arithmetic on the vector unit except in a sequence's last, partial tile;
@@ -415,6 +416,14 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
   }
 #ifdef ATTN_STAMPS
   const unsigned long long st_loop_end__ = st_prev__;
+  // [0..5] loop segments of a full item, [6] its number of key tiles, [7] unused (round 2 shipped this build without the write-out:
+  // profiles/r02_attn_stamps.txt held zeros for this kernel)
+  if (stamps && blockIdx.x % 37 == 0 && lane == 0) {
+    long long* dst = stamps + ((size_t)(blockIdx.x / 37) * 4 * NE + w8) * 8;
+    for (int i = 0; i < 6; ++i) dst[i] = (long long)st_acc__[i];
+    dst[6] = (long long)nkt;
+    dst[7] = (long long)(st_loop_end__ & 0);
+  }
 #endif
   if (MSUM) l_run = o_sum[0];      // row 0 of the third tile (lanes 0..31); lanes 32..63 hold its row 4 = 0
   } else {

@@ -4,7 +4,8 @@
 // Metric (round 3; the round-2 version printed mean(per-wave t1 - t0) / waves, which under oldest-first arbitration is 2/3 of the
 // truth at three waves and read "20 cycles per MFMA per SIMD", above the part's peak): one block per CU of 4 w waves, i.e. w waves on
 // each SIMD; every wave stamps s_memtime after a block barrier (t0) and after its loop (t1); the block's MAKESPAN is
-// max(t1) - min(t0) over its waves, in which each SIMD ran w x iters iterations.  Printed: the median over the 256 blocks of
+// max(t1) - min(t0) over its waves, in which each SIMD ran w x iters iterations.  KIND >= 20 rows no longer run the KIND-10 loop
+// first (round 2: "s_barrier 921.9" was 905 cycles of that loop + 17).  Printed: the median over the 256 blocks of
 // makespan / (iters x w x per_iter) = cycles per instruction (or per iteration) PER SIMD, next to mean(t1 - t0) / (iters x per_iter),
 // what one wave waits for its own instruction.  Check: "mfma alone" must read ~32 per SIMD at every occupancy.
 #include <hip/hip_runtime.h>
@@ -100,11 +101,19 @@ __global__ void k(float* out, long long* cyc, int iters) {
     unsigned vx = 0;
     for (int it = 0; it < iters; ++it) {
       if (KIND == 20) {
+        // all 24 reads are issued before the first result is consumed (round 2 consumed each read at once: 24 exposed LDS
+        // latencies per iteration, ~46 cycles each - a latency figure, not an issue cost)
         const char* p0 = smem + (threadIdx.x & 63) * 16;
+        uint4 qa[8];
+        uint2 qb[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const uint4 q = *reinterpret_cast<const uint4*>(p0 + i * 1024 + (it & 1) * 8192); vx ^= q.x ^ q.w; }
+        for (int i = 0; i < 8; ++i) qa[i] = *reinterpret_cast<const uint4*>(p0 + i * 1024 + (it & 1) * 8192);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const uint2 q = *reinterpret_cast<const uint2*>(p0 + i * 1024 + 16384 + (it & 1) * 8); vx ^= q.x ^ q.y; }
+        for (int i = 0; i < 16; ++i) qb[i] = *reinterpret_cast<const uint2*>(smem + (threadIdx.x & 63) * 8 + i * 512 + 16384 + (it & 1) * 8192);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vx ^= qa[i].x ^ qa[i].w;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vx ^= qb[i].x ^ qb[i].y;
       }
       if (KIND == 21) {
 #pragma unroll
