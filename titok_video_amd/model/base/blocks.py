@@ -123,9 +123,15 @@ class _Tower(nn.Module):
         old, self._pack = self._pack, None
         if old is not None and old.device.type == "cuda":
             cur = torch.cuda.current_stream(old.device)
+            build = getattr(old, "build_stream", None)
             for st in old.reader_streams.values():
                 if st != cur:
                     cur.wait_stream(st)
+                # the freed buffers return to the BUILD stream's pool: when that is not the current stream (a version change noticed
+                # inside a ForwardPipeline side stream) it must see the readers as finished too, or it could hand the memory out
+                # again while another stream is still reading the old pack
+                if build is not None and build != cur and st != build:
+                    build.wait_stream(st)
 
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
         params = self._param_list()

@@ -199,9 +199,12 @@ class BatchPlan:
         if self.device.type != "cuda":
             return
         cur = torch.cuda.current_stream(self.device)
+        build = getattr(self, "build_stream", None)
         for st in self.reader_streams.values():
             if st != cur:
                 cur.wait_stream(st)
+            if build is not None and build != cur and st != build:      # the tables return to the build stream's pool (see _Tower._retire_pack)
+                build.wait_stream(st)
 
     def attention_table(self, q_heads: int, kv_heads: int, split: Optional[bool] = None) -> torch.Tensor:
         """int32 [n,4] attention work table (sequence, first query row, q-head, mode) for this batch, XCD-aware.
