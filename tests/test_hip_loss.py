@@ -132,6 +132,11 @@ def test_bf16_losses_and_gradients_follow_the_reference_bf16_run():
     # noise in the logits enters with a positive sign and a factor 10.  Three revisions of the bf16 kernels with the same op-level
     # accuracy (tests/test_hip_ops.py) gave 2.55, 2.61 and 2.69 here against 2.36 (reference fp32) / 2.33 (reference bf16): the
     # band below is that spread, the well-conditioned terms are held tighter, and the fp32 path pins the arithmetic (3e-3, above).
+    # Round 3 (tools/loss_probe.py): the excess is NOT the deferred softmax reference (TTV_ATTN_THR=0 gives the same
+    # 2.688) and it is larger on the tape-recording forward this test runs (2.69; r1 0.0518 vs 0.0433) than on the fused inference
+    # towers (2.55; r1 0.0466): the unfused sequence rounds more intermediates to bf16, and the reference's four SEPARATE calls see
+    # x and x + noise in identical tile positions, so its rounding errors largely cancel in the difference.  The band stays at the
+    # measured spread; it is a bound on a bf16 training quantity, not a parity claim (that is the fp32 test above).
     tot, parts = mod(to(target), to(recon), disc_forward=True, gp_noise_tensors=to(noise))
     assert abs(float(tot) - float(d["disc_total"])) < 0.45
     assert abs(float(tot) - float(d["disc_total_bf16"])) < 0.45

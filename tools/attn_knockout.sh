@@ -10,6 +10,6 @@ for v in dma barrier valu lds all; do
     dma) D="-DPP_KO_DMA=1";; barrier) D="-DPP_KO_BARRIER=1";; valu) D="-DPP_KO_VALU=1";; lds) D="-DPP_KO_LDS=1";; all) D="-DPP_KO_DMA=1 -DPP_KO_BARRIER=1 -DPP_KO_VALU=1 -DPP_KO_LDS=1";;
   esac
   hipcc $FLAGS $D -c ttv_attn.hip -o build/ttv_attn_ko_$v.o
-  hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o build/ttv_gemm.o build/ttv_attn_ko_$v.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o build/libtitok_hip_ko_$v.so
+  hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o build/ttv_gemm.o build/ttv_attn_ko_$v.o build/ttv_attn64.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o build/libtitok_hip_ko_$v.so
 done
 echo "built knock-out libraries"
