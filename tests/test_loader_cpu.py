@@ -51,3 +51,20 @@ def test_worker_batches_are_deterministic_and_match_one_process(tmp_path):
     f0 = per_worker[0][0]["video"][0]
     assert first["__key__"] == per_worker[0][0]["__key__"][0]
     assert torch.equal(first["video"], f0.to(torch.float32) / 127.5 - 1.0)
+
+
+def test_host_thread_limit_respects_the_container_share():
+    """train.limit_host_threads: never more threads than the affinity mask / cgroup quota grants, never more than asked for."""
+    import os
+
+    import torch
+
+    from titok_video_amd.train import host_cpu_share, limit_host_threads
+    before = torch.get_num_threads()
+    try:
+        share = host_cpu_share()
+        assert 1 <= share <= (os.cpu_count() or 1)
+        n = limit_host_threads(3)
+        assert n == torch.get_num_threads() and 1 <= n <= min(3, share)
+    finally:
+        torch.set_num_threads(before)

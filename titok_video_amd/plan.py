@@ -62,7 +62,9 @@ def _upload(host: np.ndarray, device) -> torch.Tensor:
     if stage is None or stage.numel() < nbytes:
         stage = _pinned_stage[str(dev)] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
     view = stage[:nbytes].view(t.dtype).view(t.shape)
-    view.copy_(t)
+    # numpy, not Tensor.copy_: above 32 K elements torch's CPU copy is a parallel region of its intra-op pool, and waking that pool
+    # (128 threads on a 16-CPU container share) starves the launch path of the whole process (train.limit_host_threads)
+    np.copyto(view.numpy(), host)
     with torch.cuda.stream(cs):
         out = view.to(dev, non_blocking=True)
     cs.synchronize()

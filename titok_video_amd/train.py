@@ -60,6 +60,42 @@ def freeze_python_gc() -> None:
     gc.freeze()
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: the scheduler affinity, capped by the cgroup quota (a container sees every core of the
+    host in os.cpu_count() - 256 on the GPU boxes - while its quota is 16)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(parts[0]) // int(parts[1])))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def limit_host_threads(max_threads: int = 4) -> int:
+    """Host-side tuning for training loops (opt-in, process-wide): torch sizes its intra-op thread pool by os.cpu_count() (128
+    threads on a GPU box whose cgroup grants 16 CPUs).  The first CPU-side tensor operation above the parallel grain size wakes
+    the whole pool and its workers then spin between parallel regions: the autograd thread, the loader's upload thread and the HIP
+    runtime's own threads are starved (measured on BASELINE config #3, tools/train_host_diag.sh: hipLaunchKernel 5 -> 20 us, a
+    training step 8.1 -> 33-40 ms although the GPU work is 8 ms).  A training process has no CPU-side tensor work worth more
+    than a few threads; returns the thread count set."""
+    n = max(1, min(int(max_threads), host_cpu_share(), torch.get_num_threads()))
+    torch.set_num_threads(n)
+    return n
+
+
 def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.96, weight_decay: float = 1e-4,
                    capturable: bool = False):
     """AdamW with the reference's hyper-parameters (configs/tiny.yaml:39-46, train.py:170-190).  capturable=True keeps the step

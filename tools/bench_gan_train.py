@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from titok_video_amd.model.titok import TiTok
 from titok_video_amd.model.losses import ReconstructionLoss
 from titok_video_amd.synthetic import seeded_titok_state, seeded_tower_state, synthetic_clips
-from titok_video_amd.train import freeze_python_gc, gan_training_step, make_discriminator_optimizer, make_optimizer
+from titok_video_amd.train import freeze_python_gc, limit_host_threads, gan_training_step, make_discriminator_optimizer, make_optimizer
 B = int(os.environ.get("B", "32"))
 cfg = SimpleNamespace(
     tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=[7, 5, 5, 5, 5], encoder_size="tiny", decoder_size="tiny"),
@@ -24,6 +24,7 @@ clips = synthetic_clips([(16, 128, 128)] * B, seed=1, dtype=torch.bfloat16, devi
 counts = [128] * B
 og, od = make_optimizer(m), make_discriminator_optimizer(lm)
 freeze_python_gc()
+limit_host_threads()
 for _ in range(3):
     gan_training_step(m, lm, clips, counts, og, od)
 torch.cuda.synchronize()

@@ -38,6 +38,11 @@ def main():
     ap.add_argument("--workers", type=int, default=2, help="loader worker processes per rank (the reference uses 3, video_dataset.py:211)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--repeat-first-batch", action="store_true", help="diagnostics: every step trains on the first batch (plans cached, loader idle)")
+    ap.add_argument("--preload", action="store_true", help="diagnostics: fetch every batch of the run before the first step (loader idle during the steps)")
+    ap.add_argument("--torch-profile", default="", help="diagnostics: torch.profiler tables (CPU + GPU) of the timed steps of rank 0 -> this file")
+    ap.add_argument("--phase-times", action="store_true", help="diagnostics: host milliseconds per step spent waiting for the loader / building plans / in the step")
+    ap.add_argument("--host-profile", default="", help="write a cProfile summary of the timed steps of rank 0 to this file (diagnostics)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # own fan-out, before anything touches the GPU (reference: L.Trainer(devices=N), train.py:270-280)
         import socket
@@ -64,7 +69,7 @@ def main():
     from titok_video_amd.loader import ShardBatchLoader
     from titok_video_amd.shards import write_synthetic_shards
     from titok_video_amd.synthetic import seeded_titok_state, seeded_tower_state
-    from titok_video_amd.train import freeze_python_gc, gan_training_step, make_discriminator_optimizer, make_optimizer
+    from titok_video_amd.train import freeze_python_gc, gan_training_step, limit_host_threads, make_discriminator_optimizer, make_optimizer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +128,7 @@ def main():
     logger = CodebookLogger(4375, world_size=world)
 
     freeze_python_gc()
+    host_threads = limit_host_threads() if os.environ.get("TTV_KEEP_TORCH_THREADS") != "1" else torch.get_num_threads()
 
     def one_step(batch):
         clips, counts = batch["video"], batch["token_counts"].tolist()
@@ -137,16 +143,98 @@ def main():
 
     # loader: worker processes decode + batch, one thread uploads and normalises on the GPU a few batches ahead (titok_video_amd/loader.py)
     it = iter(equal_steps(loader.batches(device, dtype)))
+    if args.repeat_first_batch:
+        import itertools
+        first = next(it)
+        it = itertools.repeat(first)
+    if args.preload:
+        pre = [next(it) for _ in range(args.warmup + args.steps)]
+        torch.cuda.synchronize(device)
+        it = iter(pre)
+        if os.environ.get("TTV_DIAG_WARM_PLANS") == "1":      # one untimed pass over the same batches with an unbounded plan cache: the timed pass finds every plan
+            from titok_video_amd import plan as plan_mod0
+            plan_mod0._PLAN_CACHE_MAX = 1 << 20
+            for b in pre:
+                one_step(b)
+            torch.cuda.synchronize(device)
+    phase = {"loader_wait": 0.0, "get_plan": 0.0, "batch_for": 0.0}
+    if args.phase_times:
+        from titok_video_amd import plan as plan_mod
+        from titok_video_amd.model.base import blocks as blocks_mod
+
+        def timed(fn, key):
+            def w(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    phase[key] += time.perf_counter() - t
+            return w
+        for k in ("model_fwd", "loss_fwd", "backward", "clip", "opt_step", "logger", "empty_big"):
+            phase[k] = 0.0
+        model.forward = timed(model.forward, "model_fwd")
+        loss_module.forward = timed(loss_module.forward, "loss_fwd")
+        torch.Tensor.backward = timed(torch.Tensor.backward, "backward")
+        torch.nn.utils.clip_grad_norm_ = timed(torch.nn.utils.clip_grad_norm_, "clip")
+        opt_g.step = timed(opt_g.step, "opt_step")
+        opt_d.step = timed(opt_d.step, "opt_step")
+        real_empty = torch.empty
+
+        def empty(*a, **k):           # allocations above 1 MiB (tapes, workspaces): caching-allocator misses show up here
+            t = time.perf_counter()
+            out = real_empty(*a, **k)
+            if out.numel() * out.element_size() > (1 << 20):
+                phase["empty_big"] += time.perf_counter() - t
+            return out
+        torch.empty = empty
+        blocks_mod.get_plan = timed(blocks_mod.get_plan, "get_plan")
+        plan_mod.BatchPlan.batch_for = timed(plan_mod.BatchPlan.batch_for, "batch_for")
+        real_it = it
+
+        def waited():
+            while True:
+                t = time.perf_counter()
+                b = next(real_it)
+                phase["loader_wait"] += time.perf_counter() - t
+                yield b
+        it = waited()
     for _ in range(args.warmup):
         one_step(next(it))
+    for k in phase:
+        phase[k] = 0.0
+    mem0 = torch.cuda.memory_stats(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
+    tprof = None
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        tprof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=False, with_stack=False)
+        tprof.__enter__()
+    prof = None
+    if args.host_profile and rank == 0:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     n_clips, loss = 0, None
     for _ in range(args.steps):
         n, loss = one_step(next(it))
         n_clips += n
+    if tprof is not None:
+        torch.cuda.synchronize(device)
+        tprof.__exit__(None, None, None)
+        with open(args.torch_profile, "w") as f:
+            f.write(tprof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=70))
+            f.write("\n\n")
+            f.write(tprof.key_averages().table(sort_by="self_cuda_time_total", row_limit=30, max_name_column_width=70))
+    if prof is not None:
+        import pstats
+        prof.disable()
+        with open(args.host_profile, "w") as f:
+            st = pstats.Stats(prof, stream=f)
+            st.sort_stats("cumulative").print_stats(70)
+            st.sort_stats("tottime").print_stats(45)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -167,11 +255,16 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic shards",
                 "config": {"workload": "BASELINE config #3: configs/tiny.yaml, synthetic tar shards, token budget %d, K ~ U[1,128], reference G + D step "
                                        "(L1 + relativistic GAN, LPIPS off), AdamW, clip 1.0" % args.seq_len,
-                           "parallelism": f"dp{world}", "backend": args.backend if world > 1 else "none",
+                           "host_threads": host_threads, "parallelism": f"dp{world}", "backend": args.backend if world > 1 else "none",
                            "grad_allreduce": "after backward" if args.no_overlap else "overlapped with backward (per layer slice, communication stream)",
                            "allreduce_bytes_last_backward": int(red.bytes_reduced) if red is not None else 0,
                            "allreduce_slices_last_backward": int(red.slices) if red is not None else 0},
                 "loss_after_steps": float(loss), "codebook": scores}
+        if args.phase_times:
+            line["host_ms_per_step"] = {k: round(1e3 * v / args.steps, 3) for k, v in phase.items()}
+            mem1 = torch.cuda.memory_stats(device)
+            line["allocator_per_step"] = {k: (mem1[k] - mem0[k]) / args.steps for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+            line["allocator_reserved_MiB"] = mem1["reserved_bytes.all.current"] / 2**20
         print(json.dumps(line), flush=True)
     loader.close()
     if world > 1:
