@@ -57,6 +57,23 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 #define STAMP(seg_)
 #endif
 
+// Diagnostic build -DATTN_TIMELINE (tools/attn_timeline.py): wave 0 of every block writes, per table entry, the constant 100 MHz clock
+// (s_memrealtime) and the shader clock (s_memtime) at entry start / loop start / loop end / entry end plus the HW_ID and XCC_ID registers
+// to stamps[entry][8]: when and where every block ran, and the shader clock the part held meanwhile.
+#ifdef ATTN_TIMELINE
+#define TL_READ(real_, core_)                                                                          \
+  do {                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_), "=s"(core_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+#define TL_DECL unsigned long long tl_r__[4] = {0, 0, 0, 0}, tl_c__[4] = {0, 0, 0, 0}
+#define TL_MARK(i_) TL_READ(tl_r__[i_], tl_c__[i_])
+#else
+#define TL_DECL
+#define TL_MARK(i_)
+#endif
+
 // NE = table entries per block.  NE == 2 ("paired" tables, plan.attention_table): a block of 8 waves takes entries 2j and 2j+1 of
 // its XCD list - the same query rows of the two q-heads that share a kv-head - so every K / V tile is staged ONCE for both heads
 // (half the tile traffic through L2 and LDS per score).  Waves 0-3 work on the first entry, 4-7 on the second, exactly as the
@@ -67,10 +84,20 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 // when a tile raises the maximum (rare after the first tiles) the tile's scores, the running state and the start vector are shifted.
 // TAPE: the training forward - additionally writes the log-sum-exp per (row, head) and, with the gate, the ungated output.
 //
-// What bounds it: in-kernel stamps of this kernel are in profiles/r03_attn_stamps.txt (tools/attn_stamps.py; per wave and 64-key
-// tile at three waves per SIMD) - the figures round 2 quoted here had no committed source (its stamps file was empty for this
-// kernel).  Per SIMD the kernel spends ~3 800 cycles per 64 query rows x 64 keys against 1 024 cycles of MFMA; the round-3 study
-// of a 64-rows-per-wave structure (ttv_attn64.hip) shows the loop CAN run at ~2 100, and what then remains.
+// What bounds it (round-3 measurements; DESIGN.md section 4 has the table):
+//   * the shader clock the part holds under this kernel is 1.8-1.9 GHz, not the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
+//     (s_memtime against s_memrealtime inside the kernel, -DATTN_TIMELINE, profiles/r03_attn_timeline.txt);
+//   * at three waves per SIMD a wave needs ~2 650 cycles per 64-key tile (profiles/r03_attn_stamps.txt), i.e. a SIMD retires a
+//     32-query x 64-key unit every ~885 cycles against the 512 cycles of its 16 MFMAs: the unit also issues ~90 plain vector
+//     instructions (4 cycles each), 32 v_exp_f32 (8 each) and the MFMAs hold the issue port for 8 cycles each - 128 + 256 + 360
+//     = ~750 cycles of issue on a SIMD whose matrix and vector pipes overlap only partly (tools/ubench/valu_rates.hip).  Row sums
+//     on the matrix pipe (-DATTN_MSUM) trade 32 adds for 4 MFMAs and are 5 % SLOWER (65.0 vs 61.7 us);
+//   * a SIMD's throughput barely depends on how many waves it holds - 9.2 us per wave and entry at three waves, 10.4 at two, 20.2
+//     for a lone wave - and the three co-resident blocks of a CU finish staggered (22 / 32 / 42 us: vector issue is arbitrated by
+//     age), so a launch is NOT a sequence of rounds: its time grows linearly with the table (8 us + 45.5 ns per entry from 252 to
+//     2 304 entries, profiles/r03_attn_staircase.txt) and the last blocks to start run on nearly empty SIMDs (the tail);
+//   * a persistent walk of the table by 768 resident blocks (tried, tests green) is no faster, 63.4 vs 61.5 us: a fresh block's
+//     prologue is 0.8 us and its epilogue + store acknowledgement 2.5 us of 29 us, and other blocks issue meanwhile.
 // Everything off the wave's chain of dependent phases that could be moved has been:
 //   * the running reference of the softmax moves only when a score exceeds it by more than `defer_thr` (see below);
 //   * the DMA source of a tile is a scalar base (advanced per tile on the scalar unit) plus lane-constant offsets: no per-tile
@@ -92,10 +119,13 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
   const int ent = NE == 2 ? (w8 >> 2) : 0;       // which of the block's entries this wave works on
   const int wave = w8 & 3;                       // wave within the entry
   const int r = lane & 31, h = lane >> 5;
+  {
   // work table entry: (sequence, first query row, q-head, mode); sequence < 0 = padding entry of the XCD-interleaved order.
   // Paired: entries (2j, 2j+1) of list x = blockIdx % 8 sit at flat rows (2j) * 8 + x and (2j + 1) * 8 + x.
   int tix = blockIdx.x;
   bool live = true;
+  TL_DECL;
+  TL_MARK(0);
   if (NE == 2) {
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int ta = (2 * j) * 8 + x, tb = ta + 8;
@@ -221,6 +251,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
+  TL_MARK(1);
   if (mode == 0) {
   // PRE: start vectors of the two score accumulators = -m_run per lane (query); one per chain, so that neither MFMA chain has
   // to copy its start vector into its accumulator first
@@ -536,10 +567,11 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
 #undef DMA_TILE
 #undef DMA16
 
+  TL_MARK(2);
   // ---- normalise, gate, store: lane holds O[query r][32dt + 8g + 4h + 0..3] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = __builtin_amdgcn_rcpf(l_tot);
-  if (!live) return;
+  if (!live) return;      // NE == 2 only
   if (TAPE && lse_out && qrow < S && h == 0)   // natural-log LSE of the scaled scores (training tape): scale*max + ln(sum)
     lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run * (c_exp * 0.69314718055994530942f) + __logf(l_tot);
   {
@@ -581,6 +613,21 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
         const uint4 o16 = {sx[0], sy[0], sx[1], sy[1]};
         if (store) *reinterpret_cast<uint4*>(orow + dt * 32 + 16 * gp + 8 * h) = o16;
       }
+  }
+#ifdef ATTN_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // the entry's stores have been acknowledged
+  TL_MARK(3);
+  if (stamps && w8 == 0 && lane == 0) {
+    unsigned hw__, xcc__;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw__), "=s"(xcc__));
+    long long* dst = stamps + (size_t)tix * 8;
+    for (int i = 0; i < 4; ++i) dst[i] = (long long)tl_r__[i];
+    dst[4] = (long long)tl_c__[0];
+    dst[5] = (long long)tl_c__[3];
+    dst[6] = (long long)hw__;
+    dst[7] = (long long)xcc__;
+  }
+#endif
   }
 }
 

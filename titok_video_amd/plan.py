@@ -22,7 +22,7 @@ import torch
 from . import _lib
 
 QBLOCK = 128  # query rows per attention workgroup (csrc/ttv_attn.hip QB)
-ATTN_SLOTS = 1024  # attention blocks resident at once: 4 per CU (124 VGPRs, 32 KB LDS) x 256 CUs (MI355X)
+ATTN_SLOTS = 1024  # table size below which the last third of every sequence's blocks become half items (set when the kernel held 4 blocks per CU; it holds 3 = 768 since round 2 - the rule was re-measured, not re-derived: see attention_table)
 
 
 @functools.lru_cache(maxsize=8)
@@ -317,10 +317,10 @@ class BatchPlan:
         paired = 1 if (q_heads // kv_heads) % 2 == 0 and os.environ.get("TTV_ATTN_PAIRED", "0") == "1" else 0
         all_full = 1 if self._attn_all_full.get(t.data_ptr()) else 0
         # the 64-rows-per-wave kernel (ttv_attention64) for inference towers with pre-scaled q: OPT-IN (TTV_ATTN64=1).  Measured in
-        # round 3: its key loop needs 2 100 cycles per SIMD for a 64-row x 64-key step against 3 800 for the
-        # 32-rows-per-wave kernel, but at the benchmark batch (576 workgroups on 512 resident slots, 18 key tiles each) the launch is
-        # 77 us against 60 us: a block's prologue + epilogue are 18 % of its life and the 64 workgroups beyond the resident slots run
-        # a second, nearly empty round; at S = 9216 both kernels reach the same 0.37-0.40 of the MFMA peak.
+        # round 3 (profiles/r03_attn64_stamps.txt): per SIMD its key loop needs ~1 060 cycles per 32-query x
+        # 64-key unit at two waves per SIMD against ~885 for the 32-rows-per-wave kernel at three, a block's prologue + epilogue
+        # are 18 % of its life and 576 workgroups on 512 resident slots leave a tail: 77-80 us against 60-62 us at the benchmark
+        # batch; at S = 9216 both kernels reach the same 0.37 of the MFMA peak (1 119 vs 1 120 us).
         t64 = self.attention_table64(q_heads, kv_heads) if (q_heads <= 255 and os.environ.get("TTV_ATTN64", "0") == "1") else None
         return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
                           items64=t64.data_ptr() if t64 is not None else None, n_items64=int(t64.shape[0]) if t64 is not None else 0,
