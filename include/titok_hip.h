@@ -287,6 +287,13 @@ typedef struct ttv_batch {
    * inference forwards of bf16 towers whose q columns are pre-scaled run ttv_attention64 instead of ttv_attention. */
   const int32_t* items64;
   int32_t n_items64;
+  /* optional: the rotary factors as indices instead of a [L,64] fp32 table (NULL: every kernel reads `rope_cs`).  rope_ids [L,2] int32 =
+   * four uint16 per packed row: the position id of axes t, h, w (rope.py:59-67: latent i -> (i,i,i), patch (t,h,w) -> (t,h,w) + K) and
+   * the index of the identity row; rope_base fp32 [n_ids + 1, 10, 2] = (cos, sin) of inv_freq[f] * id for every id < n_ids (the values
+   * ttv_rope_table_build gathers from) with row n_ids = (1, 0).  8 bytes per row instead of 256: the width-256 to_qkv kernel gathers
+   * its factors from the L2-resident base table (bit-identical values). */
+  const int32_t* rope_ids;
+  const float* rope_base;
 } ttv_batch;
 
 /* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =

@@ -45,8 +45,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.TowerDims) == 15 * 4
     assert C.sizeof(_lib.LayerWeights) == 17 * 8   # 16 pointers + int32 mlp_pack_qkv_rows + int32 qkv_q_prescaled
     assert C.sizeof(_lib.TowerWeights) == 10 * 8
-    # + blocks64, row_seq, n_blocks64, qblocks_paired, qblocks_all_full (+ pad), items64, n_items64 (+ pad)
-    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 16 + 8 + 8
+    # + blocks64, row_seq, n_blocks64, qblocks_paired, qblocks_all_full (+ pad), items64, n_items64 (+ pad), rope_ids, rope_base
+    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 16 + 8 + 8 + 16
     src = open(HEADER).read()
     for struct, cls in [("ttv_fsq_params", _lib.FsqParams), ("ttv_tower_dims", _lib.TowerDims),
                         ("ttv_layer_weights", _lib.LayerWeights), ("ttv_tower_weights", _lib.TowerWeights),

@@ -195,6 +195,29 @@ def test_packing_invariance(dtype):
             assert torch.equal(r1[0], recon[i])
 
 
+def test_rotary_factors_by_position_id_equal_the_table_path(monkeypatch):
+    """ttv_batch.rope_ids / rope_base (8 bytes per row + the L2-resident base table, gathered inside the width-256 to_qkv kernel)
+    against the [L,64] fp32 table path (TTV_ROPE_IDS=0): the same cos / sin values, so tokens and pixels must be bit-equal."""
+    from titok_video_amd import plan as P
+    model = build(torch.bfloat16)
+    shapes = [(8, 32, 48), (4, 16, 16), (16, 64, 32), (16, 128, 128)]
+    counts = [5, 1, 17, 128]
+    clips = synthetic_clips(shapes, seed=23, dtype=torch.bfloat16, device=DEV)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TTV_ROPE_IDS", flag)
+        P._plan_cache.clear()
+        plan = P.get_plan(shapes, counts, (4, 8, 8), torch.device(DEV))
+        assert bool(plan.batch_for(4, 2).rope_ids) == (flag == "1")
+        with torch.no_grad():
+            recon, out = model(clips, counts)
+        outs.append(([r.clone() for r in recon], out["indices"].clone()))
+    P._plan_cache.clear()
+    assert torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+
+
 def test_more_clips_than_one_pointer_table_bf16():
     """Batches of more than TTV_MAX_CLIPS_PER_LAUNCH (64) clips take the stand-alone patch copy / ln_post kernels instead of
     the GEMM-fused gather / scatter: same results up to bf16 rounding of the folded gain."""

@@ -120,6 +120,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       const void* w_plain = (dt == TTV_BF16 && lw.to_qkv_qs) ? lw.to_qkv_qs : lw.to_qkv;   // inference copy with scaled q rows, if packed
       a.x = (fold_qkv || fold_gen) ? ws.x : ws.xn; a.ldx = dm; a.w = (fold_qkv || fold_gen) ? lw.to_qkv_pn : w_plain; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
       a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+      a.rope_ids = b->rope_ids; a.rope_base = b->rope_ids ? b->rope_base : nullptr;
       TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     }
     // q arrives pre-scaled when the projection used the folded weight whose q rows carry scale * log2(e)

@@ -41,6 +41,7 @@ struct GemmDev {
   const int* clip_desc; const int* patch_rows; const int* row_seq;
   const int* x_rows;   // k256: GEMM row t reads x row x_rows[t] (NULL = identity)
   const float* row_scale;   // optional [M]: acc rows are multiplied by it first (folded pre-norm of the generic-K kernels)
+  const int* rope_ids; const float* rope_base;   // optional: rotary factors by position id (k256 QKV kernel; see ttv_batch.rope_ids)
   const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma)
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
 };
@@ -762,6 +763,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
         for (int s8 = 0; s8 < 8; ++s8) bfr[j][s8] = *reinterpret_cast<const bf16x8*>(xr + s8 * 32);
       }
       if (EPI == EPI_QKV_ROPE) {
+        if (p.rope_ids) {
+          // factors by position id: the row's three ids (8 bytes) instead of its 256-byte fp32 row; the (cos, sin) pairs come from the
+          // base table (n_ids x 10 pairs, L2 / L1 resident).  Complex pair pp = 8 i + 2 kq + e of a head rotates by frequency pp / 3
+          // of axis pp % 3 (rope.py:40-54: column f * 3 + axis); pairs 30, 31 take the identity row (id slot 3).
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            int t = tile * K256_TT + wave * 32 + j * 16 + l15;
+            t = t < p.M ? t : p.M - 1;
+            const uint2 idp = *reinterpret_cast<const uint2*>(p.rope_ids + 2 * (size_t)t);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float2 cs2[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int pp = i * 8 + kq * 2 + e;
+                const int f = pp < 30 ? pp / 3 : 0, axis = pp < 30 ? pp - 3 * (pp / 3) : 3;
+                // v_perm_b32: bytes (2 axis, 2 axis + 1) of {idp.y : idp.x} into the low half, zero above
+                const uint32_t id = __builtin_amdgcn_perm(idp.y, idp.x, 0x0c0c0000u | (uint32_t)((2 * axis + 1) << 8) | (uint32_t)(2 * axis));
+                cs2[e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.rope_base) + id * 80u + (uint32_t)f * 8u);
+              }
+              rc[i][j] = make_float2(cs2[0].x, cs2[1].x);
+              rs[i][j] = make_float2(cs2[0].y, cs2[1].y);
+            }
+          }
+        } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           int t = tile * K256_TT + wave * 32 + j * 16 + l15;
@@ -772,6 +798,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
             rc[i][j] = *reinterpret_cast<const float2*>(cs + i * 8);
             rs[i][j] = *reinterpret_cast<const float2*>(cs + 32 + i * 8);
           }
+        }
         }
       }
       if (EPI == EPI_STORE_PATCH) {
@@ -1320,7 +1347,7 @@ int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, con
   TTV_CHECK_ARG(x_scale && w_scale && (uintptr_t)w_scale % 16 == 0, "gemm_fp8: scales missing / unaligned");
   TTV_CHECK_ARG((uint64_t)a.M * (uint64_t)a.ldx < (1ull << 32), "gemm_fp8: operand too large for 32-bit offsets");
   GemmDev d = {};
-  d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs;
+  d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs; d.rope_ids = a.rope_ids; d.rope_base = a.rope_base;
   d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = a.ldy; d.ldr = a.ldr; d.M = a.M; d.N = a.N; d.K = a.K; d.alpha = a.alpha;
   d.w_rows = (epi == EPI_GEGLU) ? 2 * a.N : a.N;
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end; d.eps = a.eps; d.debug = g_ttv_debug;
@@ -1355,7 +1382,7 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   TTV_CHECK_ARG(a.ldx % vec == 0 && a.ldw % vec == 0 && a.ldy % vec == 0, "gemm: leading dims must keep 16-byte row alignment");
   TTV_CHECK_ARG(((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0), "gemm: pointers must be 16-byte aligned");
   GemmDev d;
-  d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs;
+  d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs; d.rope_ids = a.rope_ids; d.rope_base = a.rope_base;
   d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = a.ldy; d.ldr = a.ldr;
   d.M = a.M; d.N = a.N; d.K = a.K; d.alpha = a.alpha;
   d.w_rows = (epi == EPI_GEGLU) ? 2 * a.N : a.N;

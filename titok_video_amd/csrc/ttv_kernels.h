@@ -52,6 +52,7 @@ struct GemmArgs {
   const void* resid; int ldr;      // [M,N] dtype
   float alpha;
   const float* rope_cs;            // [M,64]
+  const int* rope_ids; const float* rope_base;   // optional (ttv_batch.rope_ids / rope_base): the K == 256 bf16 kernel gathers its factors through them
   int rope_q_end, rope_k_begin, rope_k_end;  // column ranges [0,q_end) and [k_begin,k_end) get rotary
   int dtype;
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]

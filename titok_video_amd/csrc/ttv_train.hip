@@ -104,6 +104,7 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     GemmArgs a = {};
     a.dtype = dt; a.x = l.xn1; a.ldx = dm; a.w = lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = l.qkvg; a.ldy = nq;
     a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+    a.rope_ids = b->rope_ids; a.rope_base = b->rope_ids ? b->rope_base : nullptr;
     TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
     if (dt == TTV_BF16) {
       // one launch writes the raw output a (tape) and the gated one ag = a * sigmoid(gate) (gate applied to the stored, rounded a)

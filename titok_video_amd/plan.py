@@ -77,6 +77,19 @@ def _rope_base_device(head_dim: int, nd: int, n_ids: int, device: str):
     return torch.from_numpy(c).to(device).contiguous(), torch.from_numpy(s_).to(device).contiguous()
 
 
+@functools.lru_cache(maxsize=16)
+def _rope_base_interleaved(head_dim: int, nd: int, n_ids: int, device: str):
+    """fp32 [n_ids + 1, F, 2] = (cos, sin) of every (position id, frequency), row n_ids = (1, 0): the table the to_qkv kernel gathers
+    its rotary factors from (same values as _rope_base_table, i.e. as the reference's freqs_cis after the fp32 cast)."""
+    c, s_ = _rope_base_table(head_dim, nd, n_ids)
+    t = np.empty((n_ids + 1, c.shape[1], 2), dtype=np.float32)
+    t[:n_ids, :, 0] = c
+    t[:n_ids, :, 1] = s_
+    t[n_ids, :, 0] = 1.0
+    t[n_ids, :, 1] = 0.0
+    return torch.from_numpy(t).to(device).contiguous()
+
+
 def _rope_clip_table(grid: Tuple[int, ...], k: int, head_dim: int) -> np.ndarray:
     """fp32 [K+P, 64] = cos[32] | sin[32] for one clip; pairs beyond 3*F keep (1, 0) (rope.py:24 leaves them alone).
     Row ids: latent i -> (i,i,i); patch (t,h,w) -> (t,h,w) + K (rope.py:59-67); column f*nd + axis (interleaved)."""
@@ -144,10 +157,23 @@ class BatchPlan:
             T, H, W = self.pixel_grids[b]
             desc[b] = (T, H, W, grids[b][0], grids[b][1], grids[b][2], pbase, 3)
             pbase += sizes[b]
+        # rotary position ids per row (rope.py:59-67), four uint16 per row = two int32: (t | h << 16, w | identity << 16)
+        n_ids = 512
+        while n_ids < max(k + max(g) for g, k in zip(grids, self.token_counts)) + 1:
+            n_ids *= 2
+        self.n_rope_ids = n_ids
+        ids = np.empty((self.total_rows, 4), dtype=np.uint16)
+        ids[:, 3] = n_ids                                              # slot 3: the identity row of the base table (pairs 30, 31)
+        for b in range(B):
+            k = self.token_counts[b]
+            ids[cu[b]:cu[b] + k, :3] = np.arange(k, dtype=np.uint16)[:, None]
+            coords = np.indices(grids[b]).reshape(len(grids[b]), -1).T      # raster order (t, h, w)
+            ids[cu[b] + k:cu[b + 1], :3] = np.minimum(coords + k, n_ids - 1).astype(np.uint16)
+        rope_ids = ids.view(np.int32).reshape(-1)
         blocks64 = np.asarray([(b, r0) for b in range(B) for r0 in range(0, cu[b + 1] - cu[b], 64)], dtype=np.int32).reshape(-1, 2)
         row_seq = np.concatenate([np.full(cu[b + 1] - cu[b], b, dtype=np.int32) for b in range(B)])
         self.n_blocks64 = int(blocks64.shape[0])
-        parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1), blocks64.reshape(-1), row_seq]
+        parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1), blocks64.reshape(-1), row_seq, rope_ids]
         offs, total = [], 0
         for p in parts:
             offs.append(total)
@@ -159,9 +185,6 @@ class BatchPlan:
         base = self.int_tables.data_ptr()
         if self.device.type == "cuda":
             # gather on the device from the (cached, device-resident) base table: no per-batch trigonometry, no big upload
-            n_ids = 512
-            while n_ids < max(k + max(g) for g, k in zip(grids, self.token_counts)) + 1:
-                n_ids *= 2
             bc, bs = _rope_base_device(head_dim, len(self.patch), n_ids, str(self.device))
             self.rope_cs = torch.empty((self.total_rows, head_dim), dtype=torch.float32, device=self.device)
             rc = _lib.lib().ttv_rope_table_build(bc.data_ptr(), bs.data_ptr(), n_ids, bc.shape[1], base + 4 * offs[3], base + 4 * offs[0],
@@ -182,6 +205,11 @@ class BatchPlan:
             cu_seqlens=base + 4 * offs[0], latent_rows=base + 4 * offs[1], patch_rows=base + 4 * offs[2],
             clip_desc=base + 4 * offs[3], rope_cs=self.rope_cs.data_ptr(),
             blocks64=base + 4 * offs[4], row_seq=base + 4 * offs[5], n_blocks64=self.n_blocks64)
+        # rotary factors by position id (ttv_batch.rope_ids / rope_base): the width-256 to_qkv kernel reads 8 bytes per row and gathers
+        # from the cached base table instead of streaming the 256-byte fp32 row of rope_cs (TTV_ROPE_IDS=0: the table path, A/B)
+        if self.device.type == "cuda" and len(self.patch) == 3 and os.environ.get("TTV_ROPE_IDS", "1") != "0":
+            self._rope_base_cs = _rope_base_interleaved(head_dim, len(self.patch), n_ids, str(self.device))
+            self._base_fields.update(rope_ids=base + 4 * offs[6], rope_base=self._rope_base_cs.data_ptr())
         self._offs = offs
         self._attn = {}
         self._attn_all_full = {}
