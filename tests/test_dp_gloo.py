@@ -119,6 +119,9 @@ def _ragged_worker(rank, world, port, q):
             t = torch.ones(1)
             dist.all_reduce(t)                                 # stands for the per-step gradient all-reduce
             steps += 1
+        # the same through the CPU-side control group a RCCL run would create for the flag (forced here: the main group is gloo already)
+        steps_ctl = sum(1 for _b in equal_steps(iter(mine), _force_control_group=True))
+        assert steps_ctl == steps
         q.put((rank, fired, len(mine), steps))
     finally:
         dist.destroy_process_group()

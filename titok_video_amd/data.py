@@ -73,19 +73,39 @@ def dynamic_batches(samples, patch: Sequence[int], token_range: Sequence[int], m
         yield _collate(chunk, counts, device)
 
 
-def equal_steps(batches: Iterator[Dict], process_group=None) -> Iterator[Dict]:
+_control_groups: Dict = {}
+
+
+def _control_group(process_group=None, force: bool = False):
+    """A CPU-side (gloo) group with the ranks of `process_group` for 8-byte control collectives.  Under RCCL a flag all-reduce lives on
+    the GPU and reading it back (`flag.item()`) drains everything the rank has queued - one host synchronisation per training step.
+    Control decisions go through gloo instead: the host blocks for the other ranks' hosts only, the GPU queues stay full.  Created once
+    per group (collectively: every rank calls this at its first `equal_steps`); gloo groups are returned as they are."""
+    import torch.distributed as dist
+    if dist.get_backend(process_group) == "gloo" and not force:
+        return process_group
+    key = id(process_group) if process_group is not None else None
+    g = _control_groups.get(key)
+    if g is None:
+        ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
+        g = _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return g
+
+
+def equal_steps(batches: Iterator[Dict], process_group=None, _force_control_group: bool = False) -> Iterator[Dict]:
     """Data-parallel training loop guard: yield this rank's batches only while EVERY rank still has one.  Token-budget batching
     gives the ranks different numbers of batches for the same number of clips; the per-step gradient all-reduce must be entered
-    by all ranks or by none, so the epoch ends (collectively) when the first rank runs out - one 8-byte all-reduce per step."""
+    by all ranks or by none, so the epoch ends (collectively) when the first rank runs out - one 8-byte all-reduce per step, on a
+    CPU-side control group (no GPU synchronisation: `_control_group`)."""
     import torch.distributed as dist
     it = iter(batches)
     on = dist.is_available() and dist.is_initialized()
+    ctl = _control_group(process_group, _force_control_group) if on else None
     while True:
         nxt = next(it, None)
         if on:
-            dev = "cpu" if dist.get_backend(process_group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
-            flag = torch.tensor([0 if nxt is None else 1], dtype=torch.int64, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+            flag = torch.tensor([0 if nxt is None else 1], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
             if int(flag.item()) == 0:
                 return
         elif nxt is None:
