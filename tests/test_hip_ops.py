@@ -174,6 +174,65 @@ def test_linear_general_k_tile_heights(shape, tile):
     assert_close(y.float(), x.double() @ w.double().T, "bf16")
 
 
+@pytest.mark.parametrize("case", ["store", "geglu", "qkv_rope", "resid_bf16", "resid_f32"])
+@pytest.mark.parametrize("M", [1, 255, 300, 1025])
+def test_linear_256x256_tiles(case, M):
+    """k_gemm_bf16_t256 (256-feature x 256-token tiles, 8 waves; forced with ttv_debug_set bit 512) under every epilogue it serves,
+    against fp64 and against the 128 x 128 kernel (bit 1024 forbids the large tile)."""
+    g = torch.Generator().manual_seed(M + len(case))
+    bf = torch.bfloat16
+    code = _lib.dtype_code(bf)
+    outs = []
+    for bit in (512, 1024):
+        L().ttv_debug_set(bit)
+        try:
+            if case == "store":
+                N, K = 512, 768
+                x, w, _ = _lin_inputs(M, N, K, "bf16", 3)
+                y = torch.full((M, N), float("nan"), dtype=bf, device=DEV)
+                xd, wd = x.to(DEV), w.to(DEV)
+                _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, None, None, y.data_ptr(), N, M, N, K, code, S()), "linear")
+                ref = x.double() @ w.double().T
+            elif case == "geglu":
+                I, K = 384, 704
+                x, w, _ = _lin_inputs(M, 2 * I, K, "bf16", 4)
+                y = torch.full((M, I), float("nan"), dtype=bf, device=DEV)
+                xd, wd = x.to(DEV), w.to(DEV)
+                _lib.check(L().ttv_linear_geglu(xd.data_ptr(), K, wd.data_ptr(), K, y.data_ptr(), I, M, I, K, code, S()), "geglu")
+                h = x.double() @ w.double().T
+                a, gate = h.chunk(2, -1)
+                ref = torch.nn.functional.gelu(gate) * a
+            elif case == "qkv_rope":
+                plan = BatchPlan([(8, 32, 48), (4, 16, 24)], [3, 5], (4, 8, 8), DEV)
+                Mq, d, gq = plan.total_rows, 768, 256
+                x, w, _ = _lin_inputs(Mq, 2 * d + 2 * gq, d, "bf16", 5)
+                y = torch.full((Mq, 2 * d + 2 * gq), float("nan"), dtype=bf, device=DEV)
+                xd, wd = x.to(DEV), w.to(DEV)
+                _lib.check(L().ttv_linear_qkv_rope(xd.data_ptr(), d, wd.data_ptr(), d, y.data_ptr(), 2 * d + 2 * gq, Mq, d, gq,
+                                                   plan.rope_cs.data_ptr(), code, S()), "qkv")
+                r0 = (x.double() @ w.double().T).float()
+                q, gate, k, v = r0.split([d, d, gq, gq], dim=-1)
+                cos, sin = O.rope_table(plan.grids, plan.token_counts)
+                q = O.apply_rotary(q.unflatten(-1, (12, 64)), cos, sin).flatten(-2)
+                k = O.apply_rotary(k.unflatten(-1, (4, 64)), cos, sin).flatten(-2)
+                ref = torch.cat([q, gate, k, v], -1)
+            else:
+                f32out = case == "resid_f32"
+                N, K = 768, 2048
+                x, w, _ = _lin_inputs(M, N, K, "bf16", 6)
+                r = torch.randn(M, N, generator=torch.Generator().manual_seed(M)).to(bf)
+                y = torch.full((M, N), float("nan"), dtype=torch.float32 if f32out else bf, device=DEV)
+                xd, wd, rd = x.to(DEV), w.to(DEV), r.to(DEV)
+                _lib.check(L().ttv_linear_residual(xd.data_ptr(), K, wd.data_ptr(), K, rd.data_ptr(), N, 8.0, y.data_ptr(), N, int(f32out), M, N, K, code, S()), "resid")
+                ref = 8.0 * r.double() + x.double() @ w.double().T
+            torch.cuda.synchronize()
+        finally:
+            L().ttv_debug_set(0)
+        assert_close(y.float(), ref, "bf16")
+        outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1])     # same products in the same k order, same epilogue: bit-equal to the 128 x 128 kernel
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(300, 256, 768), (129, 768, 256), (64, 8, 256), (1, 256, 704), (513, 256, 1376)])
 def test_linear_bias_scalar(dt, shape):

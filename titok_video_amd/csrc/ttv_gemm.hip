@@ -518,6 +518,237 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16_dma(GemmDev p, int n_ftile
 }
 
 // ================================================================================================
+// 256-feature x 256-token x 64-K tiles, 8 waves (2 feature halves x 4 token quarters; a wave owns 128 features x 64 tokens = 8 x 4
+// accumulator tiles, 64 MFMAs per k-tile), both operand tiles staged by LDS-DMA into two 64 KiB stages: one block per CU.
+// Against the 128 x 128 kernel above a fragment read from LDS feeds more MFMAs (24 ds_read_b128 per 64 MFMAs instead of 16 per 32),
+// a wave issues 8 LDS-DMA instructions per 64 MFMAs instead of per 32, and a k-tile is long enough (64 MFMAs = 1 024 matrix cycles
+// per wave) for the next tile's loads to land behind it.  cdna_hip_programming.md ("the 256^2 8-phase template") is the published
+// recipe for this tile shape; the schedule here is this file's own (see the loop).
+// EPI_GEGLU: a block covers 128 output features; tile rows [128 wr, 128 wr + 64) are x features fbase + 64 wr .., rows + 64 their gates.
+// ================================================================================================
+#define T256_F 256
+#define T256_T 256
+#define T256_DEFAULT 1
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftiles) {
+  constexpr bool DUAL = (EPI == EPI_GEGLU);
+  constexpr int FOUT = DUAL ? 128 : T256_F;          // output features per block
+  __shared__ __attribute__((aligned(16))) uint4 lds[2][(T256_F + T256_T) * 8];     // 2 x 64 KiB: [stage][row * 8 + swizzled 16-byte chunk]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int fbase = (tile % n_ftiles) * FOUT;
+  const int tbase = (tile / n_ftiles) * T256_T;
+  const bf16_t* W = (const bf16_t*)p.w;
+  const bf16_t* X = (const bf16_t*)p.x;
+
+  // staging: the stage image is 512 rows of 128 bytes (256 weight rows, then 256 token rows); wave w stages rows 64 w .. 64 w + 63
+  // with 8 instructions of 8 rows each (waves 0-3 the weights, 4-7 the tokens); swizzle on the source side as in k_gemm_bf16_dma
+  const int lr = lane >> 3, lp = lane & 7;
+  uint32_t soff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (wave & 3) * 64 + i * 8 + lr;      // row within the operand's 256
+    const int ch = (lp ^ ((row >> 1) & 7)) * 8;
+    if (wave < 4) {
+      int wrow;
+      if (DUAL) { const int h = row >> 7, rr = row & 127; wrow = rr < 64 ? fbase + h * 64 + rr : p.N + fbase + h * 64 + (rr - 64); }
+      else wrow = fbase + row;
+      wrow = wrow < p.w_rows ? wrow : p.w_rows - 1;
+      soff[i] = ((uint32_t)wrow * (uint32_t)p.ldw + (uint32_t)ch) * 2u;
+    } else {
+      int xr = tbase + row;
+      xr = xr < p.M ? xr : p.M - 1;
+      soff[i] = ((uint32_t)xr * (uint32_t)p.ldx + (uint32_t)ch) * 2u;
+    }
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&lds[0][0];
+  constexpr uint32_t STAGEB = (T256_F + T256_T) * 128;
+  const bf16_t* const sbase = wave < 4 ? W : X;
+#define T2_STAGE(kt_, buf_)                                                                                      \
+  do {                                                                                                           \
+    const bf16_t* b__ = sbase + (size_t)(kt_) * BK;                                                              \
+    const uint32_t d__ = lds0 + (buf_) * STAGEB + wave * 8192;                                                   \
+    _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) {                                                        \
+      unsigned keep__;                                                                                           \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep__) : "v"(soff[i__]), "s"(b__), "s"(d__ + i__ * 1024) : "memory");                 \
+    }                                                                                                            \
+  } while (0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nk = p.K / BK;
+
+  // ---- schedule ----------------------------------------------------------------------------------------------------------
+  // A k-tile is four PHASES, one per quadrant of the wave's 128 x 64 outputs: (A0,B0) (A0,B1) (A1,B1) (A1,B0), A0 / A1 = the wave's
+  // feature tiles 0-3 / 4-7, B0 / B1 = its token tiles 0-1 / 2-3.  A phase is a short LOAD segment (this wave's LDS-DMA pieces, the
+  // wait for the fragments the quadrant needs), a barrier, a MATRIX segment (16 MFMAs at raised priority, and between them the
+  // ds_read_b128 of the fragments the NEXT phase adds - 4, 8, 0, 12 - into registers the running MFMAs do not use), a barrier.
+  // The two wave groups (wr = 0 / 1: waves w and w + 4 share a SIMD) run ONE barrier apart - group 1 takes an extra barrier first,
+  // group 0 an extra one at the end - so on every SIMD one wave is in its matrix segment while its partner is in its load segment.
+  // Staging: tile t lives in stage t & 1.  A wave issues its 8 pieces of tile t + 2 in the load segments of phase 4 of tile t (6)
+  // and phase 2 of tile t + 1 (2).
+  //   WAR: the last reads of a stage are phase 2's (A1, issued in its matrix segment and retired by the lgkmcnt(0) of phase 3's load
+  //        segment), at least one barrier before the first piece of phase 4 is issued, for either group.
+  //   RAW: the first reads of tile t + 1 are group 0's, in the matrix segment of its phase 4.  Every wave has confirmed its own pieces
+  //        of tile t + 1 (vmcnt(0)) before the barrier that opens that segment: group 0 at the top of its phase-4 load segment,
+  //        group 1 - one barrier behind - at the end of its phase-3 matrix segment.  Both waits come before the wave issues its next
+  //        pieces, so vmcnt(0) is exact, and the pieces waited for were issued 3 to 8 barrier intervals earlier.
+#define T2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define T2_BAR() do { T2_FENCE(); asm volatile("s_barrier" ::: "memory"); T2_FENCE(); } while (0)
+#define T2_LOADDONE() do { T2_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); T2_FENCE(); } while (0)
+#define T2_VMDONE() do { T2_FENCE(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2_FENCE(); } while (0)
+#define T2_PIECES(kt_, buf_, i0_, i1_)                                                                           \
+  do {                                                                                                           \
+    const bf16_t* b__ = sbase + (size_t)(kt_) * BK;                                                              \
+    const uint32_t d__ = lds0 + (buf_) * STAGEB + wave * 8192;                                                   \
+    _Pragma("unroll") for (int i__ = (i0_); i__ < (i1_); ++i__) {                                                \
+      unsigned keep__;                                                                                           \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep__) : "v"(soff[i__]), "s"(b__), "s"(d__ + i__ * 1024) : "memory");                 \
+    }                                                                                                            \
+  } while (0)
+  // fragment addresses: row 16 i + l15 (+ a multiple of 64) of an operand, 16-byte chunk (4 ks + kq) ^ ((row >> 1) & 7) - and (row >> 1) & 7 is
+  // (l15 >> 1) & 7 for every tile i, wave and operand, so two lane-constant byte offsets (ks = 0, 1) serve every read; the rest is an immediate
+  const char* const ldsb = reinterpret_cast<const char*>(&lds[0][0]);
+  const uint32_t foff0 = (uint32_t)(l15 * 128 + (((0 * 4 + kq) ^ ((l15 >> 1) & 7)) << 4)) + (uint32_t)(wr * 128 * 128);
+  const uint32_t foff1 = (uint32_t)(l15 * 128 + (((1 * 4 + kq) ^ ((l15 >> 1) & 7)) << 4)) + (uint32_t)(wr * 128 * 128);
+  const uint32_t goff0 = (uint32_t)(l15 * 128 + (((0 * 4 + kq) ^ ((l15 >> 1) & 7)) << 4)) + (uint32_t)(T256_F * 128 + wc * 64 * 128);
+  const uint32_t goff1 = (uint32_t)(l15 * 128 + (((1 * 4 + kq) ^ ((l15 >> 1) & 7)) << 4)) + (uint32_t)(T256_F * 128 + wc * 64 * 128);
+#define T2_READA(dst_, buf_, half_)                                                                              \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                        \
+      dst_[0][i__] = *reinterpret_cast<const bf16x8*>(ldsb + foff0 + ((buf_) * STAGEB + ((half_) * 4 + i__) * 2048)); \
+      dst_[1][i__] = *reinterpret_cast<const bf16x8*>(ldsb + foff1 + ((buf_) * STAGEB + ((half_) * 4 + i__) * 2048)); \
+    }                                                                                                            \
+  } while (0)
+#define T2_READB(dst_, buf_, half_)                                                                              \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__) {                                                        \
+      dst_[0][j__] = *reinterpret_cast<const bf16x8*>(ldsb + goff0 + ((buf_) * STAGEB + ((half_) * 2 + j__) * 2048)); \
+      dst_[1][j__] = *reinterpret_cast<const bf16x8*>(ldsb + goff1 + ((buf_) * STAGEB + ((half_) * 2 + j__) * 2048)); \
+    }                                                                                                            \
+  } while (0)
+#define T2_MFMA(fa_, ahalf_, fb_, bhalf_)                                                                        \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int ks__ = 0; ks__ < 2; ++ks__)                                                       \
+      _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__)                                                        \
+        _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__)                                                      \
+          acc[(ahalf_) * 4 + i__][(bhalf_) * 2 + j__] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+              fa_[ks__][i__], fb_[ks__][j__], acc[(ahalf_) * 4 + i__][(bhalf_) * 2 + j__], 0, 0, 0);              \
+  } while (0)
+  // one k-tile.  On entry FBA_ holds B0 and fa0[0] the first k-step of A0 (read during the previous tile's phase 4, or before the loop);
+  // FBB_ is free.  On exit FBB_ holds the next tile's B0 and fa0[0] its A0, first k-step.  At most 80 fragment registers are live at once
+  // (128 accumulators beside them): B0 is read twice per tile rather than kept across phases 2 and 3, and only half of the next A0 is
+  // read ahead in phase 4 (its second k-step follows at the top of phase 1, behind the first eight MFMAs).
+#define T2_READA_KS(dst_, buf_, half_, ks_)                                                                      \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__)                                                          \
+      dst_[ks_][i__] = *reinterpret_cast<const bf16x8*>(ldsb + ((ks_) ? foff1 : foff0) + ((buf_) * STAGEB + ((half_) * 4 + i__) * 2048)); \
+  } while (0)
+#define T2_TILE(kt_, buf_, FBA_, FBB_)                                                                           \
+  do {                                                                                                           \
+    /* phase 1: (A0, B0); reads the second k-step of A0 and B1 */                                                \
+    T2_LOADDONE();                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    T2_READA_KS(fa0, buf_, 0, 1);                                                                                \
+    T2_READB(FBB_, buf_, 1);                                                                                     \
+    T2_MFMA(fa0, 0, FBA_, 0);                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    T2_BAR();                                                                                                    \
+    /* phase 2: (A0, B1); the last two pieces of tile kt + 1; reads A1 */                                        \
+    if ((kt_) >= 1 && (kt_) + 1 < nk) T2_PIECES((kt_) + 1, (buf_) ^ 1, 6, 8);                                    \
+    T2_LOADDONE();                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    T2_READA(fa1, buf_, 1);                                                                                      \
+    T2_MFMA(fa0, 0, FBB_, 1);                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    T2_BAR();                                                                                                    \
+    /* phase 3: (A1, B1); reads B0 again; group 1 confirms tile kt + 1 at the end */                             \
+    T2_LOADDONE();                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    T2_READB(FBA_, buf_, 0);                                                                                     \
+    T2_MFMA(fa1, 1, FBB_, 1);                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    if (wr == 1) T2_VMDONE();                                                                                    \
+    T2_BAR();                                                                                                    \
+    /* phase 4: (A1, B0); group 0 confirms tile kt + 1; six pieces of tile kt + 2 into this tile's stage; reads the next B0 and half of the next A0 */ \
+    if (wr == 0) T2_VMDONE();                                                                                    \
+    if ((kt_) + 2 < nk) T2_PIECES((kt_) + 2, buf_, 0, 6);                                                        \
+    T2_LOADDONE();                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    if ((kt_) + 1 < nk) { T2_READB(FBB_, (buf_) ^ 1, 0); T2_READA_KS(fa0, (buf_) ^ 1, 0, 0); }                    \
+    T2_MFMA(fa1, 1, FBA_, 0);                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    T2_BAR();                                                                                                    \
+  } while (0)
+
+  // prologue: tiles 0 and 1 staged whole
+  T2_PIECES(0, 0, 0, 8);
+  if (nk > 1) T2_PIECES(1, 1, 0, 8);
+  T2_VMDONE();
+  T2_BAR();
+  if (wr == 1) T2_BAR();                // the stagger
+  bf16x8 fa0[2][4], fa1[2][4], fbx[2][2], fby[2][2];
+  T2_READB(fbx, 0, 0);
+  T2_READA_KS(fa0, 0, 0, 0);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {        // two tiles per trip: the two B register sets swap roles
+    T2_TILE(kt, 0, fbx, fby);
+    T2_TILE(kt + 1, 1, fby, fbx);
+  }
+  if (kt < nk) T2_TILE(kt, 0, fbx, fby);
+  if (wr == 0) T2_BAR();                // balances group 1's extra barrier
+#undef T2_FENCE
+#undef T2_BAR
+#undef T2_LOADDONE
+#undef T2_VMDONE
+#undef T2_PIECES
+#undef T2_READA
+#undef T2_READB
+#undef T2_READA_KS
+#undef T2_MFMA
+#undef T2_TILE
+#undef T2_STAGE
+
+  int tok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tok[j] = tbase + wc * 64 + j * 16 + l15;
+  if (DUAL) {
+    int feat[4];
+    f32x4 ax[4][4], ag[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      feat[i] = fbase + wr * 64 + i * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 4][j]; }
+    }
+    epilogue_tile<EPI, bf16_t, 4, 4>(p, tok, feat, ax, ag, kq);
+  } else {
+    // two halves of 64 features: half the epilogue's side registers (rotary factors, residual rows) live at a time
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      int feat[4];
+      f32x4 ah[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        feat[i] = fbase + wr * 128 + hf * 64 + i * 16 + kq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ah[i][j] = acc[hf * 4 + i][j];
+      }
+      epilogue_tile<EPI, bf16_t, 4, 4>(p, tok, feat, ah, ah, kq);
+    }
+  }
+}
+
+// ================================================================================================
 // Mixed bf16 / fp8 linears (BASELINE config #5): both operands in OCP e4m3 with one fp32 scale per row (token / weight row;
 // k_quant_rows_fp8), products on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales - twice the bf16 MFMA rate and half the
 // operand bytes through L2 and LDS - fp32 accumulation, the two row scales applied to the accumulator before the usual epilogue
@@ -1322,6 +1553,24 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     // both tiles by LDS-DMA when the k range is whole 64-element tiles and a lane's byte offset fits 32 bits (TTV_GEMM_DMA=0: A/B)
     static const bool use_dma = !(getenv("TTV_GEMM_DMA") && getenv("TTV_GEMM_DMA")[0] == '0');
     const bool dma_ok = use_dma && d.K % BK == 0 && (uint64_t)d.M * (uint64_t)d.ldx * 2u < (1ull << 32) && (uint64_t)d.w_rows * (uint64_t)d.ldw * 2u < (1ull << 32);
+    // large GEMMs of the wide towers: 256 x 256 tiles (k_gemm_bf16_t256) when the grid gives every CU at least one tile.  Measured at
+    // the base tower's shapes (36 864 rows, tools/gemm_t256_bench.py): w12 + GEGLU 294 -> 239 us, w3 + residual 154 -> 138, out_proj +
+    // residual 76 -> 74, to_qkv + rotary 190 -> 187, plain store 121 -> 121; bench.py --config base 97.6 -> 102.6 clips/s.  With the
+    // epilogue's stores knocked out both kernels run their k loops at 0.42-0.50 of the bf16 peak: what separates the cases is the
+    // epilogue (fp32 residual sums and rotary factors cost 35-80 us per launch).  TTV_GEMM_T256=0|1 forces (A/B)
+    static const int t256_env = getenv("TTV_GEMM_T256") ? atoi(getenv("TTV_GEMM_T256")) : -1;
+    if constexpr (EPI == EPI_STORE || EPI == EPI_QKV_ROPE || EPI == EPI_GEGLU || EPI == EPI_RESID_T || EPI == EPI_RESID_F32) {
+      const int fo = (EPI == EPI_GEGLU) ? 128 : T256_F;
+      const long tiles256 = (long)ttv_cdiv(d.N, fo) * ttv_cdiv(d.M, T256_T);
+      // ttv_debug_set bit 512 forces the 256 x 256 kernel wherever it is applicable (tests, A/B), bit 1024 forbids it
+      const bool forced = (d.debug & 512) || t256_env == 1;
+      const bool ok256 = dma_ok && d.N % fo == 0 && d.K >= 2 * BK && !(d.debug & 1024) && (forced || tiles256 >= 256);
+      if (ok256 && (forced || (t256_env < 0 && T256_DEFAULT))) {
+        hipLaunchKernelGGL((k_gemm_bf16_t256<EPI>), dim3((unsigned)tiles256), dim3(512), 0, s, d, ttv_cdiv(d.N, fo));
+        TTV_CHECK_LAUNCH("gemm_t256");
+        return TTV_OK;
+      }
+    }
     if ((cost160 < cost128 && force_tt != 128) || force_tt == 160) {
       if (dma_ok) hipLaunchKernelGGL((k_gemm_bf16_dma<EPI, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
       else hipLaunchKernelGGL((k_gemm_bf16<EPI, false, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
