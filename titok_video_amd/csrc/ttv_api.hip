@@ -138,6 +138,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
     // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs
     // of the tail kernel: 31 us against 35 us stand-alone in isolation, worse in the pipeline), so it is opt-in.
+    static const bool keel_f32sum = getenv("TTV_KEEL_F32SUM") && getenv("TTV_KEEL_F32SUM")[0] == '1';
     static const bool use_fused_mlp = !(getenv("TTV_FUSED_MLP") && getenv("TTV_FUSED_MLP")[0] == '0');
     static const bool use_fused_qkv = getenv("TTV_FUSED_QKV") && getenv("TTV_FUSED_QKV")[0] == '1';
     if (use_fused_mlp && ttvk_mlp_fused_supported(dt, dm, d->inner) && lw.mlp_pack) {
@@ -163,10 +164,20 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       o.alpha = d->alpha; o.y = ws.x; o.ldy = dm; o.norm_gain = lw.attn_post_ln; o.eps = d->eps;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, o, s));
     } else {
-      o.alpha = d->alpha; o.y = ws.y32; o.ldy = dm;
-      TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
+      // wide towers: the KEEL sum alpha * x + f(x) leaves the GEMM through HBM and a row kernel normalises it.  bf16 towers store it
+      // in the compute dtype, in place on x (a token row element is read as residual and written by the same lane) - the reference's
+      // autocast rounds that sum to bf16 as well (transformer.py:141: bf16 * alpha + bf16) -: half the bytes of the fp32 buffer on
+      // both kernels.  fp32 towers, and TTV_KEEL_F32SUM=1 (A/B), keep the fp32 buffer.
       const bool want = dt == TTV_BF16 && dm != 256 && lw.w12_pn && !f8_w12;
-      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      if (dt == TTV_BF16 && !keel_f32sum) {
+        o.alpha = d->alpha; o.y = ws.x; o.ldy = dm;
+        TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
+        TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      } else {
+        o.alpha = d->alpha; o.y = ws.y32; o.ldy = dm;
+        TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
+        TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      }
       rstd_valid = want;
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
@@ -199,10 +210,16 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
-      f3.alpha = d->alpha; f3.y = ws.y32; f3.ldy = dm;
-      TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
       const bool want = dt == TTV_BF16 && dm != 256 && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn && !(w->layers[i + 1].to_qkv_f8 && w->layers[i + 1].to_qkv_f8_scale);
-      TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      if (dt == TTV_BF16 && !keel_f32sum) {      // see the attention sub-layer above
+        f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm;
+        TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
+        TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      } else {
+        f3.alpha = d->alpha; f3.y = ws.y32; f3.ldy = dm;
+        TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
+        TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+      }
       rstd_valid = want;
     }
   }

@@ -731,8 +731,66 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
       for (int j = 0; j < 4; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 4][j]; }
     }
     epilogue_tile<EPI, bf16_t, 4, 4>(p, tok, feat, ax, ag, kq);
+  } else if (EPI == EPI_QKV_ROPE) {
+    // a wave's 128 features are two heads with the SAME rotary factors (they depend on the token and on the feature's position
+    // inside its head): loaded once - the 8-byte loads of the [L,64] table are what this epilogue costs - and applied to both
+    // halves, then stored by the plain epilogue.  Arithmetic and order as in epilogue_tile (row scale first, then the rotation).
+    const int f_first = __builtin_amdgcn_readfirstlane(fbase + wr * 128);
+    if (!(p.debug & 1) && (f_first < p.rope_q_end || (f_first >= p.rope_k_begin && f_first < p.rope_k_end))) {
+      float2 c[4][4], sn[4][4];
+      float rs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tc = tok[j] < p.M ? tok[j] : p.M - 1;
+        rs[j] = p.row_scale ? p.row_scale[tc] : 1.0f;
+        const float* cs = p.rope_cs + (size_t)tc * 64 + kq * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c[i][j] = *reinterpret_cast<const float2*>(cs + i * 8);
+          sn[i][j] = *reinterpret_cast<const float2*>(cs + 32 + i * 8);
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 a = acc[hf * 4 + i][j];
+            if (p.row_scale) a *= rs[j];
+            acc[hf * 4 + i][j] = (f32x4){a[0] * c[i][j].x - a[1] * sn[i][j].x, a[0] * sn[i][j].x + a[1] * c[i][j].x,
+                                         a[2] * c[i][j].y - a[3] * sn[i][j].y, a[2] * sn[i][j].y + a[3] * c[i][j].y};
+          }
+      GemmDev q = p;
+      q.row_scale = nullptr;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        int feat[4];
+        f32x4 ah[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          feat[i] = fbase + wr * 128 + hf * 64 + i * 16 + kq * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ah[i][j] = acc[hf * 4 + i][j];
+        }
+        epilogue_tile<EPI_STORE, bf16_t, 4, 4>(q, tok, feat, ah, ah, kq);     // bias / add_scalar are null for to_qkv
+      }
+    } else {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        int feat[4];
+        f32x4 ah[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          feat[i] = fbase + wr * 128 + hf * 64 + i * 16 + kq * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ah[i][j] = acc[hf * 4 + i][j];
+        }
+        epilogue_tile<EPI_STORE, bf16_t, 4, 4>(p, tok, feat, ah, ah, kq);
+      }
+    }
   } else {
-    // two halves of 64 features: half the epilogue's side registers (rotary factors, residual rows) live at a time
+    // two halves of 64 features: half the epilogue's side registers (residual rows) live at a time
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       int feat[4];
