@@ -233,6 +233,27 @@ def test_linear_256x256_tiles(case, M):
     assert torch.equal(outs[0], outs[1])     # same products in the same k order, same epilogue: bit-equal to the 128 x 128 kernel
 
 
+def test_linear_256x256_tiles_repeatable():
+    """Race screen of k_gemm_bf16_t256's LDS-DMA / barrier schedule (the long version is tools/gemm_t256_bench.py): the same launch
+    many times over a grid that fills the part several times, every result bit-equal to the 128 x 128 kernel's."""
+    M, N, K = 9216, 2048, 768          # 36 x 8 = 288 tiles of 256 x 256, 12 k-tiles
+    x, w, _ = _lin_inputs(M, N, K, "bf16", 11)
+    xd, wd = x.to(DEV), w.to(DEV)
+    code = _lib.dtype_code(torch.bfloat16)
+    y0 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    try:
+        L().ttv_debug_set(1024)
+        _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, None, None, y0.data_ptr(), N, M, N, K, code, S()), "linear")
+        L().ttv_debug_set(512)
+        for _ in range(40):
+            y1.fill_(float("nan"))
+            _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, None, None, y1.data_ptr(), N, M, N, K, code, S()), "linear")
+            assert torch.equal(y0, y1)
+    finally:
+        L().ttv_debug_set(0)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(300, 256, 768), (129, 768, 256), (64, 8, 256), (1, 256, 704), (513, 256, 1376)])
 def test_linear_bias_scalar(dt, shape):
