@@ -233,6 +233,29 @@ def test_linear_256x256_tiles(case, M):
     assert torch.equal(outs[0], outs[1])     # same products in the same k order, same epilogue: bit-equal to the 128 x 128 kernel
 
 
+@pytest.mark.parametrize("K", [128, 192, 256])
+@pytest.mark.parametrize("M", [255, 513])
+def test_linear_256x256_tiles_short_k(K, M):
+    """nk = 2, 3, 4 k-tiles (the kernel needs K >= 128): with two tiles the prologue stages everything and no piece is issued inside
+    the loop; with three, tile 2 is staged by the loop's phase 4 / phase 2 path exactly once.  Bit-equal to the 128 x 128 kernel."""
+    N = 512
+    x, w, _ = _lin_inputs(M, N, K, "bf16", 17 + K)
+    xd, wd = x.to(DEV), w.to(DEV)
+    code = _lib.dtype_code(torch.bfloat16)
+    outs = []
+    for bit in (512, 1024):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L().ttv_debug_set(bit)
+        try:
+            _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, None, None, y.data_ptr(), N, M, N, K, code, S()), "linear")
+            torch.cuda.synchronize()
+        finally:
+            L().ttv_debug_set(0)
+        assert_close(y.float(), x.double() @ w.double().T, "bf16")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_linear_256x256_tiles_repeatable():
     """Race screen of k_gemm_bf16_t256's LDS-DMA / barrier schedule (the long version is tools/gemm_t256_bench.py): the same launch
     many times over a grid that fills the part several times, every result bit-equal to the 128 x 128 kernel's."""

@@ -68,3 +68,44 @@ def test_host_thread_limit_respects_the_container_share():
         assert n == torch.get_num_threads() and 1 <= n <= min(3, share)
     finally:
         torch.set_num_threads(before)
+
+
+def test_a_failing_worker_raises_in_the_consumer_instead_of_ending_the_data(tmp_path):
+    """a corrupt shard (or any exception in a worker) used to look like a normal end of the epoch.  Shard 1 is
+    truncated in the middle of a member; the consumer must get LoaderError carrying the worker's traceback, after the batches of
+    the healthy worker that were already dealt."""
+    import pytest
+
+    from titok_video_amd.loader import LoaderError
+    paths = write_synthetic_shards(str(tmp_path), 2, 12, min_grid=(4, 16, 16), max_grid=(8, 32, 32), seed=5)
+    size = os.path.getsize(paths[1])
+    with open(paths[1], "r+b") as f:
+        f.truncate(size // 2 + 77)
+    ld = ShardBatchLoader(paths, workers=2, patch=(4, 8, 8), token_range=(1, 16), seq_len=96, seed=1, epochs=1, drop_last=True).start()
+    try:
+        with pytest.raises(LoaderError) as e:
+            list(ld.raw_batches())
+        assert "loader worker" in str(e.value) and "Traceback" in str(e.value)
+    finally:
+        ld.close()
+
+
+def test_a_killed_worker_is_noticed(tmp_path):
+    """A worker that dies without a message (SIGKILL: the OOM killer) raises too - by its exit code."""
+    import signal
+
+    import pytest
+
+    from titok_video_amd.loader import LoaderError
+    paths = write_synthetic_shards(str(tmp_path), 1, 8, min_grid=(4, 16, 16), max_grid=(8, 32, 32), seed=6)
+    ld = ShardBatchLoader(paths, workers=1, patch=(4, 8, 8), token_range=(1, 16), seq_len=96, seed=1, epochs=None, drop_last=True, prefetch=2).start()
+    try:
+        it = ld._raw()
+        next(it)                                   # the worker is alive and blocked on a free slot (prefetch 2, nothing released)
+        os.kill(ld._procs[0].pid, signal.SIGKILL)
+        with pytest.raises(LoaderError) as e:
+            for _ in range(8):
+                next(it)
+        assert "died without a message" in str(e.value)
+    finally:
+        ld.close()

@@ -595,8 +595,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
   // group 0 an extra one at the end - so on every SIMD one wave is in its matrix segment while its partner is in its load segment.
   // Staging: tile t lives in stage t & 1.  A wave issues its 8 pieces of tile t + 2 in the load segments of phase 4 of tile t (6)
   // and phase 2 of tile t + 1 (2).
-  //   WAR: the last reads of a stage are phase 2's (A1, issued in its matrix segment and retired by the lgkmcnt(0) of phase 3's load
-  //        segment), at least one barrier before the first piece of phase 4 is issued, for either group.
+  //   WAR: the last reads of a stage's WEIGHT rows are phase 2's (A1, issued in its matrix segment and retired by the lgkmcnt(0) of
+  //        phase 3's load segment), at least one barrier before a weight-staging wave (group 0) issues its first piece in phase 4.
+  //        The last reads of its TOKEN rows are phase 3's re-read of B0.  Group 0's are retired by the lgkmcnt(0) of its phase-4 load
+  //        segment, one barrier before the token-staging waves (group 1) reach theirs; group 1's OWN re-read is only one s_barrier
+  //        ahead of its pieces, so the phase-4 load segment retires it explicitly (s_waitcnt lgkmcnt(0)) BEFORE the pieces are issued
+  //        (until then this rested on in-order LDS issue and the DMA's latency).
   //   RAW: the first reads of tile t + 1 are group 0's, in the matrix segment of its phase 4.  Every wave has confirmed its own pieces
   //        of tile t + 1 (vmcnt(0)) before the barrier that opens that segment: group 0 at the top of its phase-4 load segment,
   //        group 1 - one barrier behind - at the end of its phase-3 matrix segment.  Both waits come before the wave issues its next
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
 #define T2_BAR() do { T2_FENCE(); asm volatile("s_barrier" ::: "memory"); T2_FENCE(); } while (0)
 #define T2_LOADDONE() do { T2_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); T2_FENCE(); } while (0)
 #define T2_VMDONE() do { T2_FENCE(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2_FENCE(); } while (0)
+#define T2_LGKDONE() do { T2_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); T2_FENCE(); } while (0)
 #define T2_PIECES(kt_, buf_, i0_, i1_)                                                                           \
   do {                                                                                                           \
     const bf16_t* b__ = sbase + (size_t)(kt_) * BK;                                                              \
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
     T2_BAR();                                                                                                    \
     /* phase 4: (A1, B0); group 0 confirms tile kt + 1; six pieces of tile kt + 2 into this tile's stage; reads the next B0 and half of the next A0 */ \
     if (wr == 0) T2_VMDONE();                                                                                    \
-    if ((kt_) + 2 < nk) T2_PIECES((kt_) + 2, buf_, 0, 6);                                                        \
+    if ((kt_) + 2 < nk) { T2_LGKDONE(); T2_PIECES((kt_) + 2, buf_, 0, 6); }                                      \
     T2_LOADDONE();                                                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                               \
     if ((kt_) + 1 < nk) { T2_READB(FBB_, (buf_) ^ 1, 0); T2_READA_KS(fa0, (buf_) ^ 1, 0, 0); }                    \
@@ -710,6 +715,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
 #undef T2_BAR
 #undef T2_LOADDONE
 #undef T2_VMDONE
+#undef T2_LGKDONE
 #undef T2_PIECES
 #undef T2_READA
 #undef T2_READB

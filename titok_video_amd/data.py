@@ -73,23 +73,41 @@ def dynamic_batches(samples, patch: Sequence[int], token_range: Sequence[int], m
         yield _collate(chunk, counts, device)
 
 
-_control_groups: Dict = {}
+_control_groups: Dict = {}       # rank tuple of the data group (None = the world) -> gloo group
 
 
-def _control_group(process_group=None, force: bool = False):
-    """A CPU-side (gloo) group with the ranks of `process_group` for 8-byte control collectives.  Under RCCL a flag all-reduce lives on
-    the GPU and reading it back (`flag.item()`) drains everything the rank has queued - one host synchronisation per training step.
-    Control decisions go through gloo instead: the host blocks for the other ranks' hosts only, the GPU queues stay full.  Created once
-    per group (collectively: every rank calls this at its first `equal_steps`); gloo groups are returned as they are."""
+def _group_key(process_group):
+    import torch.distributed as dist
+    return None if process_group is None else tuple(dist.get_process_group_ranks(process_group))
+
+
+def setup_control_group(process_group=None, force: bool = False):
+    """COLLECTIVE over the WORLD: create (once) the CPU-side gloo group that carries the 8-byte control collectives of
+    `process_group`.  `dist.new_group` must be entered by every rank of the default group, also by ranks outside `process_group`
+    and by ranks that never iterate `equal_steps` (an evaluation-only rank) - so a program with sub-groups or such ranks calls this
+    on every rank right after `init_process_group`.  When every rank of the world trains over the default group, `equal_steps`
+    calls it lazily at its first step, which is then the same collective.  Cached by the group's RANK TUPLE (not `id()`, which a
+    new group can reuse after the old one is collected); `drop_control_groups()` forgets them (call it before
+    `destroy_process_group`)."""
     import torch.distributed as dist
     if dist.get_backend(process_group) == "gloo" and not force:
         return process_group
-    key = id(process_group) if process_group is not None else None
+    key = _group_key(process_group)
     g = _control_groups.get(key)
     if g is None:
-        ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
-        g = _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        g = _control_groups[key] = dist.new_group(ranks=list(key) if key is not None else None, backend="gloo")
     return g
+
+
+def drop_control_groups() -> None:
+    _control_groups.clear()
+
+
+def _control_group(process_group=None, force: bool = False):
+    """Under RCCL a flag all-reduce lives on the GPU and reading it back (`flag.item()`) drains everything the rank has queued - one
+    host synchronisation per training step.  Control decisions go through gloo instead (`setup_control_group`): the host blocks for
+    the other ranks' hosts only, the GPU queues stay full.  gloo groups are returned as they are."""
+    return setup_control_group(process_group, force)
 
 
 def equal_steps(batches: Iterator[Dict], process_group=None, _force_control_group: bool = False) -> Iterator[Dict]:

@@ -27,6 +27,7 @@ import os
 import queue
 import tarfile
 import threading
+import traceback
 from typing import Dict, Iterator, List, Optional, Sequence
 
 import numpy as np
@@ -56,6 +57,18 @@ def raw_shard_samples(paths: Sequence[str], epochs: Optional[int] = 1) -> Iterat
         ep += 1
 
 
+class LoaderError(RuntimeError):
+    """A loader worker process or the upload thread failed; the message carries the original traceback.  Raised in the CONSUMER
+    (`raw_batches()` / `batches()`), never swallowed into a normal end-of-data."""
+
+
+class _Failure:
+    """Queue sentinel of a failed producer (picklable: it crosses the process boundary)."""
+
+    def __init__(self, where: str, text: str):
+        self.where, self.text = where, text
+
+
 def _worker_main(paths, patch, token_range, seq_len, seed, epochs, drop_last, ring, free_q, out_q, release):
     torch.set_num_threads(1)
     try:
@@ -69,8 +82,10 @@ def _worker_main(paths, patch, token_range, seq_len, seed, epochs, drop_last, ri
                 clips.append((off, t, h, w))
                 off += (n + 15) // 16 * 16
             out_q.put({"slot": slot, "clips": clips, "fps": b["fps"], "__key__": b["__key__"], "token_counts": b["token_counts"].tolist()})
+        out_q.put(None)                            # end of data: only a worker that finished its shards says so
+    except BaseException:                          # corrupt shard, a clip that does not fit its ring slot, ...: the consumer re-raises
+        out_q.put(_Failure(f"loader worker (shards {list(paths)})", traceback.format_exc()))
     finally:
-        out_q.put(None)
         release.wait()
 
 
@@ -92,6 +107,8 @@ class ShardBatchLoader:
         self.slot_bytes = int(seq_len) * int(np.prod(patch)) * 3 + 4096
         self._procs, self._queues, self._free, self._rings = [], [], [], []
         self._registered = False
+        self._pinned = False
+        self._pinned_rings: List[torch.Tensor] = []
         self._stop = threading.Event()
 
     def start(self) -> "ShardBatchLoader":
@@ -118,13 +135,34 @@ class ShardBatchLoader:
         live = list(range(self.workers))
         while live:
             for w in list(live):
-                b = self._queues[w].get()
+                b = self._get(w)
                 if b is None:
                     live.remove(w)
                     continue
                 b["worker"] = w
                 b["frames"] = [self._rings[w][b["slot"]][off:off + 3 * t * h * wd].view(t, h, wd, 3) for off, t, h, wd in b["clips"]]
                 yield b
+
+    def _get(self, w: int):
+        """Next descriptor of worker w.  A worker that failed sends a _Failure; one that died without a word (killed, segfault)
+        is noticed by its exit code - both raise LoaderError here instead of looking like the end of the data."""
+        while True:
+            try:
+                b = self._queues[w].get(timeout=1.0)
+            except queue.Empty:
+                if self._stop.is_set():
+                    return None
+                p = self._procs[w]
+                if not p.is_alive():
+                    try:                            # a last message may still be in the pipe
+                        b = self._queues[w].get(timeout=0.5)
+                    except queue.Empty:
+                        raise LoaderError(f"loader worker {w} died without a message (exit code {p.exitcode})")
+                else:
+                    continue
+            if isinstance(b, _Failure):
+                raise LoaderError(f"{b.where} failed:\n{b.text}")
+            return b
 
     def release(self, b: Dict) -> None:
         self._free[b["worker"]].put(b["slot"])
@@ -147,13 +185,16 @@ class ShardBatchLoader:
         def uploader():
             torch.cuda.set_device(device)
             up = torch.cuda.Stream(device=device)
-            if not self._registered:               # the rings become pinned host memory: uploads go straight from them
-                rt = torch.cuda.cudart()
-                self._pinned = all(int(rt.cudaHostRegister(r.data_ptr(), r.numel(), 0)) == 0 for r in self._rings)
-                self._registered = True
             staging = None
             in_flight = []                         # (event, batch descriptor): slots whose upload may still be reading
             try:
+                if not self._registered:           # the rings become pinned host memory: uploads go straight from them
+                    rt = torch.cuda.cudart()
+                    self._registered = True
+                    for r in self._rings:          # every ring is tried; the ones that succeeded are remembered for close()
+                        if int(rt.cudaHostRegister(r.data_ptr(), r.numel(), 0)) == 0:
+                            self._pinned_rings.append(r)
+                    self._pinned = len(self._pinned_rings) == len(self._rings)
                 for b in self._raw():
                     if self._stop.is_set():
                         break
@@ -187,20 +228,42 @@ class ShardBatchLoader:
                     if not self._pinned:
                         ev.synchronize()           # the staging buffer is reused by the next batch
                     in_flight.append((ev, b))
-                    out_q.put(({"video": clips, "fps": b["fps"], "__key__": b["__key__"],
-                                "token_counts": torch.tensor(b["token_counts"], dtype=torch.int32)}, ev))
+                    item = ({"video": clips, "fps": b["fps"], "__key__": b["__key__"],
+                             "token_counts": torch.tensor(b["token_counts"], dtype=torch.int32)}, ev)
+                    while not self._stop.is_set():  # a consumer that stopped early must not leave this thread blocked in put()
+                        try:
+                            out_q.put(item, timeout=0.2)
+                            break
+                        except queue.Full:
+                            pass
                 for ev0, b0 in in_flight:
                     ev0.synchronize()
                     self.release(b0)
-            finally:
-                out_q.put(None)
+                in_flight = []
+                out_q.put(None)                    # end of data
+            except BaseException:
+                for ev0, _b0 in in_flight:         # nothing may still be reading a ring when close() unregisters it
+                    ev0.synchronize()
+                fail = _Failure("loader upload thread", traceback.format_exc())
+                while True:                        # the sentinel must arrive: make room if the consumer is not reading
+                    try:
+                        out_q.put_nowait(fail)
+                        break
+                    except queue.Full:
+                        try:
+                            out_q.get_nowait()
+                        except queue.Empty:
+                            pass
 
         th = threading.Thread(target=uploader, daemon=True)
         th.start()
+        self._uploader, self._upload_q = th, out_q
         while True:
             item = out_q.get()
             if item is None:
                 return
+            if isinstance(item, _Failure):
+                raise LoaderError(f"{item.where} failed:\n{item.text}")
             batch, ev = item
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ev)
@@ -210,6 +273,18 @@ class ShardBatchLoader:
 
     def close(self) -> None:
         self._stop.set()
+        # the upload thread first: it may hold copies in flight out of the rings; drain its queue so a blocked put() returns, join it,
+        # and only then unregister the rings
+        th, q = getattr(self, "_uploader", None), getattr(self, "_upload_q", None)
+        if th is not None:
+            while th.is_alive():
+                try:
+                    while True:
+                        q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.2)
+            self._uploader = self._upload_q = None
         if getattr(self, "_release", None) is not None:
             self._release.set()
         for p in self._procs:
@@ -219,8 +294,11 @@ class ShardBatchLoader:
                 p.terminate()
         for p in self._procs:
             p.join(timeout=5)
-        if self._registered and getattr(self, "_pinned", False):
+        if self._pinned_rings:                     # every ring that WAS registered, also when a later registration failed
             rt = torch.cuda.cudart()
-            for r in self._rings:
+            if torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+            for r in self._pinned_rings:
                 rt.cudaHostUnregister(r.data_ptr())
+        self._pinned_rings = []
         self._procs, self._queues, self._free, self._rings, self._registered = [], [], [], [], False

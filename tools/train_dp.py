@@ -54,7 +54,8 @@ def main():
             port = sk.getsockname()[1]
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                   env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                                           MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(args.gpus)]
+                                           MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                           TTV_RUN_TOKEN="%d_%d_%d" % (os.getpid(), port, int(time.time() * 1e3)))) for r in range(args.gpus)]
         codes = [p.wait() for p in procs]
         if any(codes):
             raise SystemExit(f"train_dp.py --gpus {args.gpus}: rank exit codes {codes}")
@@ -80,16 +81,36 @@ def main():
 
     # ---- shards (rank 0 writes, everybody reads its own) and the loader's worker processes: BEFORE this process touches the GPU
     # (the workers are forked; the ranks meet on a marker file, not on a collective)
-    shard_dir = args.shards or os.path.join(tempfile.gettempdir(), "ttv_shards_%s" % os.environ.get("MASTER_PORT", "single"))
+    # The directory is unique per run: the launcher of the ranks (this script's own fan-out, or whatever started them) hands every
+    # rank the same TTV_RUN_TOKEN; under torchrun, where MASTER_PORT is the constant 29500 and may be reused by the next run, the
+    # token falls back to TORCHELASTIC_RUN_ID + the launcher's pid.  Rank 0 writes the shards into a temporary sibling directory and
+    # renames it into place (atomic), then writes the token into the marker; the other ranks wait for a marker holding THEIR token, so
+    # a directory left behind by an earlier run is never read while rank 0 rewrites it.  Rank 0 removes it at exit.
+    token = os.environ.get("TTV_RUN_TOKEN") or "%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("MASTER_PORT", "single"),
+                                                            os.getppid() if world > 1 else os.getpid())
+    shard_dir = args.shards or os.path.join(tempfile.gettempdir(), "ttv_shards_%s" % token)
     n_shards = args.n_shards or 2 * world
     marker = os.path.join(shard_dir, ".written")
     if not args.shards:
         if rank == 0:
-            write_synthetic_shards(shard_dir, n_shards, args.clips_per_shard, seed=11)
-            open(marker, "w").close()
+            import atexit
+            import shutil
+            shutil.rmtree(shard_dir, ignore_errors=True)            # a stale directory of the same name (token reuse): marker goes first
+            staging = shard_dir + ".writing.%d" % os.getpid()
+            shutil.rmtree(staging, ignore_errors=True)
+            write_synthetic_shards(staging, n_shards, args.clips_per_shard, seed=11)
+            with open(os.path.join(staging, ".written"), "w") as f:
+                f.write(token)
+            os.rename(staging, shard_dir)
+            atexit.register(shutil.rmtree, shard_dir, ignore_errors=True)
         else:
             t_wait = time.time()
-            while not os.path.exists(marker):
+            while True:
+                try:
+                    if open(marker).read() == token:
+                        break
+                except OSError:
+                    pass
                 if time.time() - t_wait > 600:
                     raise SystemExit("train_dp.py: rank 0 never finished writing the shards")
                 time.sleep(0.05)
@@ -107,6 +128,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        from titok_video_amd.data import setup_control_group
+        setup_control_group()                     # collective over the world: the gloo group of equal_steps' control flag
 
     # ---- model, loss module (discriminator), optimisers: configs/tiny.yaml
     levels = [7, 5, 5, 5, 5]
@@ -269,6 +292,8 @@ def main():
     loader.close()
     if world > 1:
         dist.barrier()
+        from titok_video_amd.data import drop_control_groups
+        drop_control_groups()
         dist.destroy_process_group()
 
 
