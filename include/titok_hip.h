@@ -76,6 +76,11 @@ int ttv_vq_l2_argmin(const void* z, int dtype, int ldz, const void* codebook, in
                      int32_t* indices, float* best_dist, void* workspace, int64_t workspace_bytes, void* stream);
 /* straight-through lookup: codes[r] = codebook[indices[r]] (the value the decoder sees; gradients pass to z unchanged). */
 int ttv_vq_lookup(const void* codebook, int dtype, int ldc, const int32_t* indices, int rows, int C, void* codes, int ldo, void* stream);
+/* Backward of the lookup with respect to the codebook: dcodebook[indices[r], :] += dcodes[r, :] (fp32 accumulation, float atomics; the
+ * caller zeroes dcodebook [N, C], ldc).  With codes = codebook[idx] + (z - stopgrad(z)) this is the codebook's gradient of the
+ * straight-through quantiser named by BASELINE.json's north_star; the encoder's is the identity (FSQ's round_ste, fsq.py:48-51, is the
+ * reference's instance of the same estimator). */
+int ttv_vq_lookup_backward(const void* dcodes, int dtype, int ld, const int32_t* indices, int rows, int C, float* dcodebook, int ldc, void* stream);
 
 /* ---- mixed bf16 / fp8 linears (BASELINE config #5; not a reference feature: the reference runs bf16 autocast) -------------
  * Row-wise OCP e4m3 quantisation: y = gain ? RMSNorm(x) * gain (eps) : x;  scales[r] = max|y_r| / 448;  out[r] = e4m3(y_r / scales[r]).
@@ -87,6 +92,21 @@ int ttv_quant_rows_fp8(const void* in, int dtype, int ld_in, const float* gain, 
  * 2 GEGLU (wq [2N, K], y[:, f] = gelu(acc[:, N+f]) * acc[:, f], as ttv_linear_geglu). */
 int ttv_linear_fp8(const void* xq, int ldx, const float* x_scale, const void* wq, int ldw, const float* w_scale, void* y, int ldy, int M, int N,
                    int K, int epilogue, const float* rope_cs, int d_model, int gqa_dim, void* stream);
+
+/* Block-scaled (OCP MX) e4m3 quantisation of rows [rows, width] (dtype bf16 / fp32, width % 128 == 0): q[r, k] = round_e4m3(y / 2^E),
+ * one E8M0 byte E + 127 per 32 consecutive k, E = ceil(log2(max|block| / 448)); with row_scales != NULL (weights) y = in / row_scales[r],
+ * row_scales[r] = max|row| / 448, else y = in.  mx: ttv_mx_scale_bytes_per_row(width) bytes per row, block b = k / 32 at byte
+ * (b & 3) * nkp + (b >> 2), nkp = round_up(width / 128, 4) (the order the MFMA lanes of ttv_linear_fp8_mx read them in).
+ * Not a reference feature (the reference runs bf16 autocast, configs/tiny.yaml:70): BASELINE.json configs[4] "mixed bf16/fp8 MFMA". */
+int64_t ttv_mx_scale_bytes_per_row(int width);
+int ttv_quant_mx_fp8(const void* in, int dtype, int ld_in, void* out, int ld_out, void* mx, float* row_scales, int rows, int width, void* stream);
+/* y[M,N] (bf16) = epilogue( (xq * 2^Ex) (wq * 2^Ew)^T * x_row_scale[m] * w_row_scale[n] ) on v_mfma_scale_f32_16x16x128_f8f6f4 with the
+ * block scales as the instruction's scale operands; x_row_scale / w_row_scale may be NULL (= 1).  epilogue 0 store, 1 qkv + rotary
+ * (as ttv_linear_fp8), 2 GEGLU (wq [2N, K]), 3 y = alpha * resid + acc (resid [M,N] bf16, ldr; y may alias resid).
+ * Replaces the linears of transformer.py:47-56,86-104 in the mixed-precision configuration. */
+int ttv_linear_fp8_mx(const void* xq, int ldx, const void* x_mx, const float* x_row_scale, const void* wq, int ldw, const void* w_mx,
+                      const float* w_row_scale, void* y, int ldy, int M, int N, int K, int epilogue, const float* rope_cs, int d_model,
+                      int gqa_dim, const void* resid, int ldr, float alpha, void* stream);
 
 /* ---- single ops (exported for parity tests; the tower entry points below chain them) ------------------ */
 
@@ -244,6 +264,15 @@ typedef struct ttv_layer_weights {
    * (ttv_quant_rows_fp8).  When non-NULL the pre-norm output is quantised per token and the two projections run on the fp8 MFMA. */
   const void* to_qkv_f8; const float* to_qkv_f8_scale;
   const void* w12_f8; const float* w12_f8_scale;
+  /* optional block-scaled (MX) fp8 linears - ALL FOUR linears of the layer on the fp8 MFMA (round 4): when every pointer below and the
+   * four e4m3 images are non-NULL (bf16 towers, width != 256, width % 128 == 0, inner % 128 == 0) the layer quantises each linear's
+   * input with ttv_quant_mx_fp8 (one E8M0 scale per 32 consecutive elements) and runs ttv_linear_fp8_mx.  The images then hold
+   * ttv_quant_mx_fp8(W', row factors) with W' = to_qkv * pre_ln gain (q rows pre-scaled) / w12 * ffd_norm gain / out_proj / w3: the
+   * pre-norm is folded (its rstd is the activation's per-row factor in the epilogue), `*_f8_scale` are the weight rows' fp32 factors,
+   * `*_mx` the block scales in ttv_quant_mx_fp8's layout. */
+  const void* to_qkv_mx; const void* w12_mx;
+  const void* out_proj_f8; const float* out_proj_f8_scale; const void* out_proj_mx;
+  const void* w3_f8; const float* w3_f8_scale; const void* w3_mx;
 } ttv_layer_weights;
 
 typedef struct ttv_tower_weights {
@@ -439,7 +468,8 @@ int ttv_sq_err_accumulate(void* const* recon, void* const* target, const int32_t
  * This is the only process-global state in the library and it is off by default. */
 int ttv_prof_begin(int kernel_class, int max_records);
 /* Diagnostics for kernel ablation timing / tests (never set in product use): bit0 = GEMM epilogues skip their stores;
- * bit7 (128) / bit8 (256) = force the 160- / 128-token tile of the general-K GEMM instead of the grid-balance choice. */
+ * bit7 (128) / bit8 (256) = force the 160- / 128-token tile of the general-K GEMM instead of the grid-balance choice.
+ * The flags belong to the CALLING HOST THREAD (thread-local): launches made by other threads are unaffected. */
 int ttv_debug_set(int flags);
 /* Diagnostics: device buffer (>= 256 int64) that instrumented kernels fill with s_memtime stamps of block 0; NULL = off. */
 int ttv_debug_stamps(void* device_buffer);

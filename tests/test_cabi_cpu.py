@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     # sizes follow from the field lists in include/titok_hip.h (4-byte ints/floats, 8-byte pointers, natural alignment)
     assert C.sizeof(_lib.FsqParams) == 4 + 6 * 4 * _lib.TTV_MAX_FSQ
     assert C.sizeof(_lib.TowerDims) == 15 * 4
-    assert C.sizeof(_lib.LayerWeights) == 17 * 8   # 16 pointers + int32 mlp_pack_qkv_rows + int32 qkv_q_prescaled
+    assert C.sizeof(_lib.LayerWeights) == 25 * 8   # 24 pointers (8 of them the MX fp8 images, round 4) + int32 mlp_pack_qkv_rows + int32 qkv_q_prescaled
     assert C.sizeof(_lib.TowerWeights) == 10 * 8
     # + blocks64, row_seq, n_blocks64, qblocks_paired, qblocks_all_full (+ pad), items64, n_items64 (+ pad), rope_ids, rope_base
     assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 16 + 8 + 8 + 16

@@ -142,3 +142,162 @@ def test_base_towers_with_fp8_linears_stay_within_the_stated_tolerance():
           f"bf16+fp8 {int((res[True][1] != ref_idx).sum())} of {ref_idx.numel()}; decoder rel. error bf16 {r16:.4f} | bf16+fp8 {r8:.4f}")
     assert not torch.equal(res[False][0], res[True][0])          # the fp8 path really ran
     assert e8 < 0.25 and r8 < 0.12
+
+
+# ---- block-scaled (MX) e4m3: round 4 ----------------------------------------------------------------------------------------------
+def quant_mx(x, row_scaled=False):
+    lib, S = _lib.lib(), _lib.stream_ptr(torch.device(DEV))
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=DEV)
+    mx = torch.zeros((rows, int(lib.ttv_mx_scale_bytes_per_row(K))), dtype=torch.uint8, device=DEV)
+    rs = torch.empty(rows, dtype=torch.float32, device=DEV) if row_scaled else None
+    _lib.check(lib.ttv_quant_mx_fp8(x.data_ptr(), _lib.dtype_code(x.dtype), x.stride(0), q.data_ptr(), K, mx.data_ptr(), _lib.ptr(rs), rows, K, S), "quant_mx")
+    return q, mx, rs
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("K", [128, 768, 2048])
+@pytest.mark.parametrize("row_scaled", [False, True])
+def test_quant_mx_fp8_matches_the_oracle_bit_for_bit(dtype, K, row_scaled):
+    """Elements, E8M0 bytes (in the library's lane-major layout) and row factors of k_quant_mx_fp8 against oracle/fp8_oracle.py: rows
+    with blocks 1e-4 .. 1e4 apart (the case block scales exist for), an all-zero row, an all-zero block, exact powers of two."""
+    from oracle import fp8_oracle as F
+    g = torch.Generator().manual_seed(K + int(row_scaled))
+    rows = 131
+    x = torch.randn(rows, K, generator=g) * torch.exp(4 * torch.randn(rows, K // 32, generator=g)).repeat_interleave(32, 1)
+    x[3] = 0
+    x[5, 32:64] = 0
+    x[6] = 448.0 * 2.0 ** torch.randint(-6, 6, (K,), generator=g).float()
+    x = x.to(dtype)
+    q, mx, rs = quant_mx(x.to(DEV), row_scaled)
+    rq, re, rrs = F.mx_quantize(x, row_scaled)
+    if row_scaled:
+        assert torch.equal(rs.cpu(), rrs)
+    assert torch.equal(mx.cpu(), F.mx_scale_layout(re))
+    assert torch.equal(q.cpu(), rq)
+    # and the format's accuracy, wherever a block's scale leaves the element in e4m3's normal range: half an ulp = 2^-4 relative
+    deq = F.mx_dequantize(rq, re, rrs)
+    xf = x.double()
+    blk_floor = (2.0 ** (re.double() - 127 - 6)).repeat_interleave(32, 1) * (rrs.double()[:, None] if row_scaled else 1.0)
+    assert float(((deq - xf).abs() / (xf.abs() + blk_floor)).max()) <= 2 ** -4 + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 768), (300, 768, 2048), (36864, 256, 128), (129, 640, 1664)])
+def test_linear_fp8_mx_is_exact_on_the_quantised_operands(M, N, K):
+    """k_gemm_fp8_dma<.., MX>: the block scales reach the right lanes of v_mfma_scale_f32_16x16x128_f8f6f4 (data with block maxima
+    spread over 2^±6, so a scale applied to the wrong block is an error of orders of magnitude) - against the float64 product of the
+    dequantised operands; row factors on both sides / on neither."""
+    from oracle import fp8_oracle as F
+    lib, S = _lib.lib(), _lib.stream_ptr(torch.device(DEV))
+    g = torch.Generator().manual_seed(M + N + K)
+    spread = lambda r: torch.exp2(torch.randint(-6, 7, (r, K // 32), generator=g).float()).repeat_interleave(32, 1)
+    x = (torch.randn(M, K, generator=g) * spread(M)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * spread(N) * K ** -0.5).to(torch.bfloat16)
+    xq, xmx, _ = quant_mx(x.to(DEV))
+    wq, wmx, wrs = quant_mx(w.to(DEV), True)
+    xrs = (0.5 + torch.rand(M, generator=g)).to(DEV)
+    rq, re, _ = F.mx_quantize(x)
+    wq_o, we_o, wrs_o = F.mx_quantize(w, True)
+    assert torch.equal(xq.cpu(), rq) and torch.equal(wq.cpu(), wq_o)
+    rows = torch.arange(0, M, max(1, M // 256))
+    xd = F.mx_dequantize(rq[rows], re[rows])
+    wd = F.mx_dequantize(wq_o, we_o, wrs_o)
+    for use_rows in (True, False):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        wq2, wmx2, _ = (wq, wmx, None) if use_rows else quant_mx(w.to(DEV), False)
+        _lib.check(lib.ttv_linear_fp8_mx(xq.data_ptr(), K, xmx.data_ptr(), xrs.data_ptr() if use_rows else None, wq2.data_ptr(), K, wmx2.data_ptr(),
+                                         wrs.data_ptr() if use_rows else None, y.data_ptr(), N, M, N, K, 0, None, 0, 0, None, 0, 0.0, S), "fp8_mx")
+        if use_rows:
+            ref = (xd * xrs.cpu().double()[rows, None]) @ wd.t()
+        else:
+            w2q, w2e, _ = F.mx_quantize(w)
+            ref = xd @ F.mx_dequantize(w2q, w2e).t()
+        got = y.cpu()[rows].double()
+        assert float((got - ref).norm() / ref.norm()) < 3e-3, use_rows       # the bf16 rounding of the output only
+        assert float(((got - ref).abs() / (ref.abs() + 1e-2 * ref.abs().mean())).max()) < 2e-2
+
+
+def test_linear_fp8_mx_epilogues():
+    """GEGLU, to_qkv + rotary and the residual epilogue (alpha * resid + acc, in place) on block-scaled operands."""
+    from oracle import fp8_oracle as F
+    from titok_video_amd.plan import BatchPlan
+    lib, S = _lib.lib(), _lib.stream_ptr(torch.device(DEV))
+    g = torch.Generator().manual_seed(9)
+    plan = BatchPlan([(8, 32, 48), (4, 16, 16)], [40, 24], (4, 8, 8), DEV)
+    M, d, gq, I = plan.total_rows, 768, 256, 2048
+    x = torch.randn(M, d, generator=g).to(torch.bfloat16)
+    xq, xmx, _ = quant_mx(x.to(DEV))
+    rq, re, _ = F.mx_quantize(x)
+    xd = F.mx_dequantize(rq, re)
+
+    def weight(n, k):
+        w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16)
+        q, mx, rs = quant_mx(w.to(DEV), True)
+        return (q, mx, rs), F.mx_dequantize(*F.mx_quantize(w, True))
+    (wq, wmx, wrs), wd = weight(2 * I, d)
+    h = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.ttv_linear_fp8_mx(xq.data_ptr(), d, xmx.data_ptr(), None, wq.data_ptr(), d, wmx.data_ptr(), wrs.data_ptr(), h.data_ptr(), I, M, I, d, 2,
+                                     None, 0, 0, None, 0, 0.0, S), "geglu")
+    u = xd @ wd.t()
+    ref = torch.nn.functional.gelu(u[:, I:]) * u[:, :I]
+    assert float((h.cpu().double() - ref).norm() / ref.norm()) < 4e-3
+    # to_qkv + rotary
+    nq = 2 * d + 2 * gq
+    (wq, wmx, wrs), wd = weight(nq, d)
+    y = torch.empty(M, nq, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.ttv_linear_fp8_mx(xq.data_ptr(), d, xmx.data_ptr(), None, wq.data_ptr(), d, wmx.data_ptr(), wrs.data_ptr(), y.data_ptr(), nq, M, nq, d, 1,
+                                     plan.rope_cs.data_ptr(), d, gq, None, 0, 0.0, S), "qkv")
+    ref = (xd @ wd.t()).float()
+    cs = plan.rope_cs.cpu()
+    for lo, hi in ((0, d), (2 * d, 2 * d + gq)):
+        ref[:, lo:hi] = O.apply_rotary(ref[:, lo:hi].reshape(M, -1, 64), cs[:, :32], cs[:, 32:]).reshape(M, -1)
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) < 4e-3
+    # w3-shaped: K = 2048 -> d, y = 24 * resid + acc written over resid
+    hq_in = torch.randn(M, I, generator=g).to(torch.bfloat16)
+    hq, hmx, _ = quant_mx(hq_in.to(DEV))
+    hd = F.mx_dequantize(*F.mx_quantize(hq_in)[:2])
+    (wq, wmx, wrs), wd = weight(d, I)
+    resid = torch.randn(M, d, generator=g).to(torch.bfloat16)
+    yr = resid.clone().to(DEV)
+    _lib.check(lib.ttv_linear_fp8_mx(hq.data_ptr(), I, hmx.data_ptr(), None, wq.data_ptr(), I, wmx.data_ptr(), wrs.data_ptr(), yr.data_ptr(), d, M, d, I, 3,
+                                     None, 0, 0, yr.data_ptr(), d, 24.0, S), "resid")
+    ref = 24.0 * resid.double() + hd @ wd.t()
+    assert float((yr.cpu().double() - ref).norm() / ref.norm()) < 4e-3
+
+
+def _base_cfg(levels):
+    return SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(patch_size=[4, 8, 8], fsq_levels=levels, encoder_size="base", decoder_size="base")))
+
+
+def test_base_towers_with_mx_fp8_linears_stay_within_the_stated_tolerance():
+    """Whole base-size towers with ALL FOUR linears of every layer on the block-scaled fp8 MFMA (`fp8_linears = "mx"`), against the bf16
+    towers and the fp32 oracle.  Stated tolerance: e4m3 keeps 3 mantissa bits whatever the scale granularity, so the error is that of
+    round 2's row-scaled pair plus the two added linears': mean |pre-rounding FSQ value error| < 0.30, decoder reconstructions within
+    15 % relative - token indices are NOT preserved (printed)."""
+    levels = [8, 8, 8, 6, 5]
+    cfg = _base_cfg(levels)
+    sd = seeded_titok_state(3, "base", "base", gain=3.0)
+    shapes, counts = [(4, 16, 16), (8, 16, 24), (4, 32, 16)], [16, 24, 20]
+    clips_cpu = synthetic_clips(shapes, seed=13)
+    with torch.no_grad():
+        ref_recon, ref_idx, _z, ref_b = O.titok_forward(clips_cpu, counts, sd, levels, "base", "base")
+    res = {}
+    for mode in (False, True, "mx"):
+        m = TiTok(cfg)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV, torch.bfloat16).eval()
+        m.encoder.fp8_linears = m.decoder.fp8_linears = mode
+        clips = [c.to(DEV, torch.bfloat16) for c in clips_cpu]
+        with torch.no_grad():
+            codes, od = m.encode(clips, counts, want_bounded=True)
+            recon = m.decode(O.fsq_indices_to_codes(ref_idx, levels).to(DEV, torch.bfloat16), counts, shapes)
+        res[mode] = (m.last_bounded.cpu(), od["indices"].cpu(), torch.cat([r.float().cpu().flatten() for r in recon]))
+    ref_flat = torch.cat([r.flatten() for r in ref_recon])
+    for mode in res:
+        e = float((res[mode][0] - ref_b).abs().mean())
+        r = float((res[mode][2] - ref_flat).norm() / ref_flat.norm())
+        print(f"base towers, fp8_linears={mode!s:5}: mean |bounded err| {e:.4f}; index mismatches vs fp32 {int((res[mode][1] != ref_idx).sum())} of "
+              f"{ref_idx.numel()}; decoder rel. error {r:.4f}")
+    assert not torch.equal(res[False][0], res["mx"][0]) and not torch.equal(res[True][0], res["mx"][0])      # the MX path really ran
+    assert float((res["mx"][0] - ref_b).abs().mean()) < 0.30
+    assert float((res["mx"][2] - ref_flat).norm() / ref_flat.norm()) < 0.15

@@ -43,7 +43,9 @@ class NextQkv(C.Structure):
 class LayerWeights(C.Structure):
     _fields_ = [("pre_ln", vp), ("to_qkv", vp), ("out_proj", vp), ("ffd_norm", vp), ("w12", vp), ("w3", vp),
                 ("attn_post_ln", vp), ("ffd_post_ln", vp), ("to_qkv_pn", vp), ("w12_pn", vp), ("mlp_pack", vp), ("mlp_pack_qkv_rows", i32), ("qkv_q_prescaled", i32),
-                ("to_qkv_qs", vp), ("to_qkv_f8", vp), ("to_qkv_f8_scale", vp), ("w12_f8", vp), ("w12_f8_scale", vp)]
+                ("to_qkv_qs", vp), ("to_qkv_f8", vp), ("to_qkv_f8_scale", vp), ("w12_f8", vp), ("w12_f8_scale", vp),
+                ("to_qkv_mx", vp), ("w12_mx", vp), ("out_proj_f8", vp), ("out_proj_f8_scale", vp), ("out_proj_mx", vp),
+                ("w3_f8", vp), ("w3_f8_scale", vp), ("w3_mx", vp)]
 
 
 class TowerWeights(C.Structure):
@@ -90,8 +92,13 @@ SYMBOLS = {
     "ttv_vq_workspace_bytes": (C.c_int64, [C.c_int]),
     "ttv_vq_l2_argmin": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, vp]),
     "ttv_vq_lookup": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ttv_vq_lookup_backward": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ttv_quant_rows_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, f32, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "ttv_linear_fp8": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "ttv_mx_scale_bytes_per_row": (C.c_int64, [C.c_int]),
+    "ttv_quant_mx_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "ttv_linear_fp8_mx": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                    vp, C.c_int, f32, vp]),
     "ttv_rmsnorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, f32, vp]),
     "ttv_rope_apply": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ttv_linear": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

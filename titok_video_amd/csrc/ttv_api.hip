@@ -19,7 +19,7 @@ void ttv_set_error(const char* fmt, ...) {
 
 // ---- measurement hook ----
 int g_ttv_prof_class = 0;
-int g_ttv_debug = 0;
+thread_local int g_ttv_debug = 0;     // per host thread: a thread that forces a kernel variant (tests, A/B tools) does not change what another thread launches
 long long* g_ttv_stamps = nullptr;   // diagnostics: device buffer for in-kernel clock stamps (ttv_debug_stamps)
 static hipEvent_t* g_prof_start = nullptr;
 static hipEvent_t* g_prof_stop = nullptr;
@@ -46,6 +46,7 @@ static inline int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 struct TowerWs {
   char *x, *xn, *qkv, *ao, *h, *pa, *pb;
+  char *f8, *f8mx;   // block-scaled fp8 image of the running linear's input [L, max(width, inner)] and its E8M0 scales
   float* y32;
   float* rstd;     // [L] row statistic of a folded pre-norm (generic-width bf16 towers)
   int64_t total;
@@ -68,6 +69,12 @@ static TowerWs carve(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
   w.pa = take(P * pd * e);        // encoder: gathered patches; decoder: proj_out output
   w.pb = take(P * d->width * e);  // encoder: proj_in output;   decoder: ln_post output
   w.rstd = (float*)take(L * 4);
+  w.f8 = w.f8mx = nullptr;
+  if (d->dtype == TTV_BF16 && d->width != 256 && d->width % 128 == 0) {      // the towers that can run the block-scaled fp8 linears
+    const int64_t wide = d->width > d->inner ? d->width : d->inner;
+    w.f8 = take(L * wide);
+    w.f8mx = take(L * (wide / 128 + 4) * 4);
+  }
   w.total = off;
   return w;
 }
@@ -84,6 +91,46 @@ static int check_dims(const ttv_tower_dims* d, const ttv_batch* b) {
   return TTV_OK;
 }
 
+// One layer with all four linears on the block-scaled fp8 MFMA (BASELINE config #5; ttv_layer_weights.to_qkv_mx ...): every linear's
+// input is quantised by k_quant_mx_fp8, the pre-norm gains live in the weight images and the rstd of the pre-norm is the activation's
+// per-row factor in the GEMM epilogue; attention, the KEEL sums and norms stay bf16 / fp32 as in the bf16 tower.
+static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, const ttv_batch* b, const TowerWs& ws, int i, bool& rstd_valid,
+                        bool attn_pipe, hipStream_t s) {
+  const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
+  if (!rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
+  TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  GemmArgs a = {};
+  a.dtype = dt; a.x = ws.f8; a.ldx = dm; a.w = lw.to_qkv_f8; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
+  a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
+  TTV_TRY(ttvk_gemm_fp8(EPI_QKV_ROPE, a, ws.rstd, lw.to_qkv_f8_scale, s, ws.f8mx, lw.to_qkv_mx));
+  const bool q_scaled = lw.qkv_q_prescaled != 0;
+  TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
+                         TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
+                             (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
+  TTV_TRY(ttvk_quant_mx_fp8(ws.ao, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  GemmArgs o = {};
+  o.dtype = dt; o.x = ws.f8; o.ldx = dm; o.w = lw.out_proj_f8; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
+  o.alpha = i == 0 ? 1.f : d->alpha; o.y = ws.x; o.ldy = dm;
+  TTV_TRY(ttvk_gemm_fp8(EPI_RESID_T, o, nullptr, lw.out_proj_f8_scale, s, ws.f8mx, lw.out_proj_mx));
+  if (i > 0) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, ws.rstd));
+  else TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
+  TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  GemmArgs f = {};
+  f.dtype = dt; f.x = ws.f8; f.ldx = dm; f.w = lw.w12_f8; f.ldw = dm; f.M = L; f.N = I; f.K = dm; f.y = ws.h; f.ldy = I;
+  TTV_TRY(ttvk_gemm_fp8(EPI_GEGLU, f, ws.rstd, lw.w12_f8_scale, s, ws.f8mx, lw.w12_mx));
+  TTV_TRY(ttvk_quant_mx_fp8(ws.h, dt, I, ws.f8, I, ws.f8mx, nullptr, L, I, s));
+  GemmArgs f3 = {};
+  f3.dtype = dt; f3.x = ws.f8; f3.ldx = I; f3.w = lw.w3_f8; f3.ldw = I; f3.M = L; f3.N = dm; f3.K = I; f3.resid = ws.x; f3.ldr = dm;
+  f3.alpha = i == 0 ? 1.f : d->alpha; f3.y = ws.x; f3.ldy = dm;
+  TTV_TRY(ttvk_gemm_fp8(EPI_RESID_T, f3, nullptr, lw.w3_f8_scale, s, ws.f8mx, lw.w3_mx));
+  rstd_valid = false;
+  if (i > 0) {
+    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, ws.rstd));
+    rstd_valid = true;
+  }
+  return TTV_OK;
+}
+
 // One ResidualAttentionBlock stack (reference transformer.py:126-146) on ws.x in place.
 static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const TowerWs& ws, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
@@ -93,6 +140,13 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   static const bool attn_pipe = getenv("TTV_ATTN_PIPE") && getenv("TTV_ATTN_PIPE")[0] == '1';   // opt-in pipelined attention kernel
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
+    static const bool keel_f32 = getenv("TTV_KEEL_F32SUM") && getenv("TTV_KEEL_F32SUM")[0] == '1';
+    if (dt == TTV_BF16 && dm != 256 && dm % 128 == 0 && d->inner % 128 == 0 && !keel_f32 && lw.to_qkv_f8 && lw.to_qkv_mx && lw.w12_f8 && lw.w12_mx &&
+        lw.out_proj_f8 && lw.out_proj_mx && lw.w3_f8 && lw.w3_mx) {
+      TTV_TRY(run_layer_mx(d, lw, b, ws, i, rstd_valid, attn_pipe, s));
+      qkv_ready = false;
+      continue;
+    }
     // ---- attention sub-layer (transformer.py:85-104) ----
     // mixed bf16 / fp8 (config #5): the pre-norm output is quantised to e4m3 per token (into the xn buffer: L x dm bytes of values,
     // then L fp32 scales) and the projection runs on the fp8 MFMA; everything downstream is unchanged
@@ -261,10 +315,40 @@ int ttv_vq_lookup(const void* codebook, int dtype, int ldc, const int32_t* indic
   return ttvk_vq_lookup(codebook, dtype, ldc, indices, rows, C, codes, ldo, (hipStream_t)stream);
 }
 
+int ttv_vq_lookup_backward(const void* dcodes, int dtype, int ld, const int32_t* indices, int rows, int C, float* dcodebook, int ldc, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (dcodes && indices && dcodebook), "vq_lookup_backward: null buffer");
+  TTV_CHECK_ARG(ld >= C && ldc >= C, "vq_lookup_backward: leading dims smaller than the codebook dim");
+  return ttvk_vq_lookup_bwd(dcodes, dtype, ld, indices, rows, C, dcodebook, ldc, (hipStream_t)stream);
+}
+
 int ttv_quant_rows_fp8(const void* in, int dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
                        int width, void* stream) {
   TTV_CHECK_ARG(rows == 0 || (in && out && scales), "quant_rows_fp8: null buffer");
   return ttvk_quant_rows_fp8(in, dtype, ld_in, gain, eps, out, ld_out, scales, rows, width, (hipStream_t)stream);
+}
+
+int64_t ttv_mx_scale_bytes_per_row(int width) { return ttvk_mx_scale_ld(width); }
+
+int ttv_quant_mx_fp8(const void* in, int dtype, int ld_in, void* out, int ld_out, void* mx, float* row_scales, int rows, int width, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (in && out && mx), "quant_mx_fp8: null buffer");
+  TTV_CHECK_ARG(ld_in >= width && ld_out >= width, "quant_mx_fp8: leading dims smaller than the width");
+  return ttvk_quant_mx_fp8(in, dtype, ld_in, out, ld_out, mx, row_scales, rows, width, (hipStream_t)stream);
+}
+
+int ttv_linear_fp8_mx(const void* xq, int ldx, const void* x_mx, const float* x_row_scale, const void* wq, int ldw, const void* w_mx,
+                      const float* w_row_scale, void* y, int ldy, int M, int N, int K, int epilogue, const float* rope_cs, int d_model,
+                      int gqa_dim, const void* resid, int ldr, float alpha, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (xq && wq && y && x_mx && w_mx), "linear_fp8_mx: null buffer");
+  TTV_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "linear_fp8_mx: epilogue 0 (store), 1 (qkv + rotary), 2 (GEGLU) or 3 (alpha * resid + acc)");
+  GemmArgs a = {};
+  a.dtype = TTV_BF16; a.x = xq; a.ldx = ldx; a.w = wq; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy;
+  if (epilogue == 1) {
+    TTV_CHECK_ARG(rope_cs && N == 2 * d_model + 2 * gqa_dim, "linear_fp8_mx: qkv epilogue needs rope_cs and N = 2 d_model + 2 gqa_dim");
+    a.rope_cs = rope_cs; a.rope_q_end = d_model; a.rope_k_begin = 2 * d_model; a.rope_k_end = 2 * d_model + gqa_dim;
+  }
+  if (epilogue == 3) { a.resid = resid; a.ldr = ldr; a.alpha = alpha; }
+  return ttvk_gemm_fp8(epilogue == 0 ? EPI_STORE : epilogue == 1 ? EPI_QKV_ROPE : epilogue == 2 ? EPI_GEGLU : EPI_RESID_T, a, x_row_scale,
+                       w_row_scale, (hipStream_t)stream, x_mx, w_mx);
 }
 
 int ttv_linear_fp8(const void* xq, int ldx, const float* x_scale, const void* wq, int ldw, const float* w_scale, void* y, int ldy, int M, int N,

@@ -966,15 +966,20 @@ __global__ __launch_bounds__(256) void k_outer_small(const TA* __restrict__ a, i
 int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int b_dt, int ldb, const int* b_rows, float* dw, int lddw,
                      int transpose_out, int rows, int d, hipStream_t s) {
   if (rows == 0 || !dw) return TTV_OK;
-  TTV_CHECK_ARG(C <= TTV_MAX_FSQ, "outer_small: C");
+  TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_TOKEN, "outer_small: C");
   const int rpb = 64;
   dim3 grid(ttv_cdiv(rows, rpb));
-#define OS(TA, TB) hipLaunchKernelGGL((k_outer_small<TA, TB>), grid, dim3(256), 0, s, (const TA*)a, lda, C, (const TB*)b, ldb, b_rows, dw, lddw, transpose_out, rows, d, rpb)
-  if (a_dt == TTV_F32 && b_dt == TTV_F32) OS(float, float);
-  else if (a_dt == TTV_F32 && b_dt == TTV_BF16) OS(float, bf16_t);
-  else if (a_dt == TTV_BF16 && b_dt == TTV_F32) OS(bf16_t, float);
-  else OS(bf16_t, bf16_t);
+  // the kernel keeps TTV_MAX_FSQ partial sums per thread: wider tokens (the L2 quantiser's, up to TTV_MAX_TOKEN) go in column chunks
+  for (int c0 = 0; c0 < C; c0 += TTV_MAX_FSQ) {
+    const int cn = C - c0 < TTV_MAX_FSQ ? C - c0 : TTV_MAX_FSQ;
+    float* dwc = transpose_out ? dw + c0 : dw + (size_t)c0 * lddw;
+#define OS(TA, TB) hipLaunchKernelGGL((k_outer_small<TA, TB>), grid, dim3(256), 0, s, (const TA*)a + c0, lda, cn, (const TB*)b, ldb, b_rows, dwc, lddw, transpose_out, rows, d, rpb)
+    if (a_dt == TTV_F32 && b_dt == TTV_F32) OS(float, float);
+    else if (a_dt == TTV_F32 && b_dt == TTV_BF16) OS(float, bf16_t);
+    else if (a_dt == TTV_BF16 && b_dt == TTV_F32) OS(bf16_t, float);
+    else OS(bf16_t, bf16_t);
 #undef OS
+  }
   TTV_CHECK_LAUNCH("outer_small");
   return TTV_OK;
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- optional HIP-event bracketing of one kernel class (ttv_prof_begin / ttv_prof_end) ----------------
 extern int g_ttv_prof_class;
-extern int g_ttv_debug;
+extern thread_local int g_ttv_debug;
 extern long long* g_ttv_stamps;
 struct TtvProfScope {
   int slot;

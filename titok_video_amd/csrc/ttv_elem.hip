@@ -182,6 +182,76 @@ int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* ga
 }
 
 // ------------------------------------------------------------------------------------------------
+// MX (OCP microscaling) e4m3 quantisation for the block-scaled fp8 linears (BASELINE config #5): every 32 consecutive elements of a
+// row share one E8M0 scale 2^E, E = ceil(log2(max|block| / 448)) (the smallest power of two that brings the block into e4m3's range);
+// q = round_e4m3(y / 2^E).  The scale bytes are what v_mfma_scale_f32_16x16x128_f8f6f4 takes as its per-lane scale operand
+// (k_gemm_fp8_dma<.., MX>).  Optional per-row fp32 factor (weights: row_scales[r] = max|row| / 448, blocks then scale the row-normalised
+// values, E <= 0); activations pass NULL - their per-row factor is the rstd of the folded pre-norm, applied by the GEMM epilogue.
+// Scale layout (this library's, chosen for the GEMM's lanes): block b = k / 32 of row r lives at mx[r * ld_mx + (b & 3) * nkp + (b >> 2)],
+// nkp = round_up(d / 128, 4), ld_mx = 4 * nkp: lane group kq = b & 3 of the MFMA finds the bytes of four consecutive 128-element
+// k-tiles in one aligned dword.  One wave per row, 4 elements per lane and step (a block = 8 lanes: three DPP-free xor shuffles).
+// ------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void k_quant_mx_fp8(const TI* __restrict__ in, int ld_in, uint8_t* __restrict__ out, int ld_out,
+                                                      uint8_t* __restrict__ mx, int ld_mx, int nkp, float* __restrict__ row_scales,
+                                                      int rows, int d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (r >= rows) return;
+  const TI* p = in + (size_t)r * ld_in;
+  float inv_row = 1.0f;
+  if (row_scales) {                                 // weights (packed once): a first pass for the row maximum, the row is re-read from the cache
+    float amax = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const f32x4 y = Vec4<TI>::load(p + c);
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+    }
+    amax = wave_max(amax);
+    const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    inv_row = 1.0f / scale;
+    if (lane == 0) row_scales[r] = scale;
+  }
+  uint8_t* q = out + (size_t)r * ld_out;
+  uint8_t* m = mx + (size_t)r * ld_mx;
+  // d is a multiple of 128: in the last step lanes 0-31 may work while 32-63 idle, never a part of an 8-lane block
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 y = Vec4<TI>::load(p + c) * inv_row;
+    float a = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+    a = fmaxf(a, __shfl_xor(a, 1));
+    a = fmaxf(a, __shfl_xor(a, 2));
+    a = fmaxf(a, __shfl_xor(a, 4));
+    // E8M0 byte = biased exponent of the smallest power of two >= a / 448
+    const uint32_t tb = __float_as_uint(a * (1.0f / 448.0f));
+    int byte = (int)((tb >> 23) & 0xFF) + ((tb & 0x7FFFFF) ? 1 : 0);
+    byte = a > 0.f ? (byte < 1 ? 1 : (byte > 254 ? 254 : byte)) : 127;
+    const float inv_blk = __uint_as_float((uint32_t)(254 - byte) << 23);      // 2^-(byte - 127)
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0] * inv_blk, y[1] * inv_blk, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2] * inv_blk, y[3] * inv_blk, w, true);
+    *reinterpret_cast<int*>(q + c) = w;
+    if ((lane & 7) == 0) {
+      const int b = c >> 5;
+      m[(b & 3) * nkp + (b >> 2)] = (uint8_t)byte;
+    }
+  }
+}
+
+int64_t ttvk_mx_scale_ld(int d) { return 4 * (int64_t)((d / 128 + 3) / 4 * 4); }
+
+int ttvk_quant_mx_fp8(const void* in, int in_dtype, int ld_in, void* out, int ld_out, void* mx, float* row_scales, int rows, int d, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(d > 0 && d % 128 == 0, "quant_mx_fp8: width %d must be a multiple of 128", d);
+  TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && (uintptr_t)out % 4 == 0 && (uintptr_t)mx % 4 == 0, "quant_mx_fp8: alignment");
+  const int nkp = (d / 128 + 3) / 4 * 4;
+  dim3 grid(ttv_cdiv(rows, ROWS_PER_BLOCK));
+  if (in_dtype == TTV_BF16) hipLaunchKernelGGL((k_quant_mx_fp8<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, ld_in, (uint8_t*)out, ld_out, (uint8_t*)mx, 4 * nkp, nkp, row_scales, rows, d);
+  else if (in_dtype == TTV_F32) hipLaunchKernelGGL((k_quant_mx_fp8<float>), grid, dim3(256), 0, s, (const float*)in, ld_in, (uint8_t*)out, ld_out, (uint8_t*)mx, 4 * nkp, nkp, row_scales, rows, d);
+  else { ttv_set_error("quant_mx_fp8: bad dtype"); return TTV_ERR_INVALID; }
+  TTV_CHECK_LAUNCH("quant_mx_fp8");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rows that hold RMSNorm(mask_token * ones(d)) * gain: encoder latent rows (blocks.py:96), decoder patch rows
 // (blocks.py:167).  Every such row is the same vector; mean(m^2) over a constant row is m^2.
 // ------------------------------------------------------------------------------------------------

@@ -42,7 +42,9 @@ struct GemmDev {
   const int* x_rows;   // k256: GEMM row t reads x row x_rows[t] (NULL = identity)
   const float* row_scale;   // optional [M]: acc rows are multiplied by it first (folded pre-norm of the generic-K kernels)
   const int* rope_ids; const float* rope_base;   // optional: rotary factors by position id (k256 QKV kernel; see ttv_batch.rope_ids)
-  const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma)
+  const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma; either may be NULL with MX)
+  const uint8_t* x_mx; const uint8_t* w_mx;     // MX block scales (E8M0, k_quant_mx_fp8's layout), ld_mx bytes per row
+  int ld_mx;
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
 };
 
@@ -823,7 +825,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
 // ================================================================================================
 typedef int v8i32 __attribute__((ext_vector_type(8)));
 
-template <int EPI, int NJ>
+// MX = true (round 4): both operands carry one E8M0 scale per 32 CONSECUTIVE k elements (k_quant_mx_fp8), fed to the instruction's
+// per-lane scale operands: lane group kq then has to hold k = 32 kq .. 32 kq + 31 of the 128-element tile, so the LDS-DMA source side
+// places source chunk 2c at image chunk c and 2c + 1 at c + 4 (the reads stay chunk kq and kq + 4: the conflict-free pattern); a
+// lane's scale bytes of four consecutive k-tiles arrive as one dword per operand row (prefetched one group ahead) and are shifted
+// into byte 0.  The per-row fp32 factors become optional (activations: the rstd of the folded pre-norm, p.x_scale; weights: the
+// row factor of the pack).
+template <int EPI, int NJ, bool MX = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
   constexpr int FT = DUAL ? 64 : TF;
@@ -849,14 +857,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
     if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
     else wr = fbase + row;
     wr = wr < p.w_rows ? wr : p.w_rows - 1;
-    woff[i] = (uint32_t)wr * (uint32_t)p.ldw + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
+    const int ch = lp ^ ((row >> 1) & 7);
+    woff[i] = (uint32_t)wr * (uint32_t)p.ldw + (uint32_t)((MX ? ((ch & 3) * 2 + (ch >> 2)) : ch) * 16);
   }
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int row = wave * (8 * XI) + i * 8 + lr;
     int xr = tbase + row;
     xr = xr < p.M ? xr : p.M - 1;
-    xoff[i] = (uint32_t)xr * (uint32_t)p.ldx + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
+    const int ch = lp ^ ((row >> 1) & 7);
+    xoff[i] = (uint32_t)xr * (uint32_t)p.ldx + (uint32_t)((MX ? ((ch & 3) * 2 + (ch >> 2)) : ch) * 16);
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&lds[0][0];
   constexpr uint32_t BUFB = (TF + TTK) * 128;
@@ -884,12 +894,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
 
   const int l15 = lane & 15, kq = lane >> 4;
   const int nk = p.K / BK8;
+  // MX: scale dwords (4 k-tiles each) of this lane's operand rows; `cur` serves the running group of four k-tiles, `nxt` the next
+  uint32_t sa_cur[4], sb_cur[NJ], sa_nxt[4], sb_nxt[NJ];
+  const uint8_t* sa_ptr[4];
+  const uint8_t* sb_ptr[NJ];
+  if constexpr (MX) {
+    const int nkp = p.ld_mx >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int wrow = (DUAL ? (i < 2 ? fbase + wf * 32 + i * 16 : p.N + fbase + wf * 32 + (i - 2) * 16) : fbase + wf * 64 + i * 16) + l15;
+      wrow = wrow < p.w_rows ? wrow : p.w_rows - 1;
+      sa_ptr[i] = p.w_mx + (size_t)wrow * p.ld_mx + kq * nkp;
+      sa_cur[i] = *reinterpret_cast<const uint32_t*>(sa_ptr[i]);
+      sa_nxt[i] = sa_cur[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int xr = tbase + wt * (16 * NJ) + j * 16 + l15;
+      xr = xr < p.M ? xr : p.M - 1;
+      sb_ptr[j] = p.x_mx + (size_t)xr * p.ld_mx + kq * nkp;
+      sb_cur[j] = *reinterpret_cast<const uint32_t*>(sb_ptr[j]);
+      sb_nxt[j] = sb_cur[j];
+    }
+  }
   G8_STAGE(0, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) G8_STAGE(kt + 1, buf ^ 1);
+    if constexpr (MX) {
+      if ((kt & 3) == 0) {
+        if (kt) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sa_cur[i] = sa_nxt[i];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) sb_cur[j] = sb_nxt[j];
+        }
+        if (kt + 4 < nk) {                          // the next group's bytes: in flight for four k-tiles
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sa_nxt[i] = *reinterpret_cast<const uint32_t*>(sa_ptr[i] + kt + 4);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) sb_nxt[j] = *reinterpret_cast<const uint32_t*>(sb_ptr[j] + kt + 4);
+        }
+      }
+    }
     v8i32 a[4], b[NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -905,12 +954,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
       const uint4 lo = lds[buf][TF * 8 + brow * 8 + (kq ^ sw)], hi = lds[buf][TF * 8 + brow * 8 + ((kq + 4) ^ sw)];
       b[j] = (v8i32){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
     }
+    if constexpr (MX) {
+      const int sh = (kt & 3) * 8;
+      int sa[4], sb[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sa[i] = (int)(sa_cur[i] >> sh);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sb[j] = (int)(sb_cur[j] >> sh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0 /* byte 0 */, sa[i], 0, sb[j]);
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0 /* A: fp8 e4m3 */, 0 /* B: fp8 e4m3 */,
                                                                       0, 0x7F7F7F7F /* E8M0 1.0 */, 0, 0x7F7F7F7F);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
@@ -923,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
-    sx[j] = p.x_scale[tok[j] < p.M ? tok[j] : p.M - 1];
+    sx[j] = (MX && !p.x_scale) ? 1.0f : p.x_scale[tok[j] < p.M ? tok[j] : p.M - 1];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -931,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
     if (DUAL) f = (i < 2 ? fbase + wf * 32 + i * 16 : p.N + fbase + wf * 32 + (i - 2) * 16) + kq * 4;
     else f = fbase + wf * 64 + i * 16 + kq * 4;
     f = f + 3 < p.w_rows ? f : p.w_rows - 4;
-    const f32x4 sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + f);
+    const f32x4 sw4 = (MX && !p.w_scale) ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(p.w_scale + f);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1651,13 +1714,18 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
 }
 
 // y[M,N] (bf16) = dequant(xq[M,K] e4m3, x_scale[M]) @ dequant(wq[N(or 2I),K] e4m3, w_scale)^T with the EPI_STORE / EPI_QKV_ROPE / EPI_GEGLU epilogues
-int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, const float* w_scale, hipStream_t s) {
+int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, const float* w_scale, hipStream_t s, const void* x_mx, const void* w_mx) {
   if (a.M == 0 || a.N == 0) return TTV_OK;
-  TTV_CHECK_ARG(epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU, "gemm_fp8: epilogue must be STORE, QKV_ROPE or GEGLU");
+  const bool mx = x_mx || w_mx;
+  TTV_CHECK_ARG(epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU || (mx && epi == EPI_RESID_T),
+                "gemm_fp8: epilogue must be STORE, QKV_ROPE or GEGLU (block-scaled operands: RESID_T as well)");
   TTV_CHECK_ARG(a.K > 0 && a.K % 128 == 0 && a.N % 8 == 0, "gemm_fp8: K %% 128, N %% 8");
   TTV_CHECK_ARG(a.ldx % 16 == 0 && a.ldw % 16 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0),
                 "gemm_fp8: 16-byte row alignment");
-  TTV_CHECK_ARG(x_scale && w_scale && (uintptr_t)w_scale % 16 == 0, "gemm_fp8: scales missing / unaligned");
+  if (mx) TTV_CHECK_ARG(x_mx && w_mx && (uintptr_t)x_mx % 4 == 0 && (uintptr_t)w_mx % 4 == 0 && (!w_scale || (uintptr_t)w_scale % 16 == 0),
+                        "gemm_fp8: block scales of both operands needed (4-byte aligned)");
+  else TTV_CHECK_ARG(x_scale && w_scale && (uintptr_t)w_scale % 16 == 0, "gemm_fp8: scales missing / unaligned");
+  if (epi == EPI_RESID_T) TTV_CHECK_ARG(a.resid && a.ldr % 4 == 0, "gemm_fp8: residual missing");
   TTV_CHECK_ARG((uint64_t)a.M * (uint64_t)a.ldx < (1ull << 32), "gemm_fp8: operand too large for 32-bit offsets");
   GemmDev d = {};
   d.x = a.x; d.w = a.w; d.y = a.y; d.bias = a.bias; d.add_scalar = a.add_scalar; d.resid = a.resid; d.rope_cs = a.rope_cs; d.rope_ids = a.rope_ids; d.rope_base = a.rope_base;
@@ -1665,19 +1733,25 @@ int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, con
   d.w_rows = (epi == EPI_GEGLU) ? 2 * a.N : a.N;
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end; d.eps = a.eps; d.debug = g_ttv_debug;
   d.x_scale = x_scale; d.w_scale = w_scale;
+  d.x_mx = (const uint8_t*)x_mx; d.w_mx = (const uint8_t*)w_mx; d.ld_mx = 4 * ((a.K / 128 + 3) / 4 * 4);
   if (epi == EPI_QKV_ROPE) TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 128 == 0 && a.rope_k_begin % 128 == 0 && a.rope_k_end % 128 == 0, "gemm_fp8: rotary ranges must be multiples of 128 columns");
   const int ft = (epi == EPI_GEGLU) ? 64 : TF;
   const int nf = ttv_cdiv(d.N, ft), nt = ttv_cdiv(d.M, TT), nt160 = ttv_cdiv(d.M, 160);
   const long cost128 = (long)ttv_cdiv(nf * nt, 512) * 128, cost160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
   const bool t160 = cost160 < cost128;
-  const int kc = epi == EPI_STORE ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : TTV_KC_GEMM_GEGLU;
+  const int kc = epi == EPI_STORE ? TTV_KC_GEMM_STORE : epi == EPI_QKV_ROPE ? TTV_KC_GEMM_QKV : epi == EPI_GEGLU ? TTV_KC_GEMM_GEGLU : TTV_KC_GEMM_RESID;
   TtvProfScope prof(kc, s);
-#define F8_LAUNCH(E_)                                                                                              \
+#define F8_LAUNCH(E_, MX_)                                                                                         \
   do {                                                                                                              \
-    if (t160) hipLaunchKernelGGL((k_gemm_fp8_dma<E_, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);                \
-    else hipLaunchKernelGGL((k_gemm_fp8_dma<E_, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);                        \
+    if (t160) hipLaunchKernelGGL((k_gemm_fp8_dma<E_, 5, MX_>), dim3(nf * nt160), dim3(256), 0, s, d, nf);           \
+    else hipLaunchKernelGGL((k_gemm_fp8_dma<E_, 4, MX_>), dim3(nf * nt), dim3(256), 0, s, d, nf);                   \
   } while (0)
-  if (epi == EPI_STORE) F8_LAUNCH(EPI_STORE); else if (epi == EPI_QKV_ROPE) F8_LAUNCH(EPI_QKV_ROPE); else F8_LAUNCH(EPI_GEGLU);
+  if (mx) {
+    if (epi == EPI_STORE) F8_LAUNCH(EPI_STORE, true); else if (epi == EPI_QKV_ROPE) F8_LAUNCH(EPI_QKV_ROPE, true);
+    else if (epi == EPI_GEGLU) F8_LAUNCH(EPI_GEGLU, true); else F8_LAUNCH(EPI_RESID_T, true);
+  } else {
+    if (epi == EPI_STORE) F8_LAUNCH(EPI_STORE, false); else if (epi == EPI_QKV_ROPE) F8_LAUNCH(EPI_QKV_ROPE, false); else F8_LAUNCH(EPI_GEGLU, false);
+  }
 #undef F8_LAUNCH
   TTV_CHECK_LAUNCH("gemm_fp8");
   return TTV_OK;

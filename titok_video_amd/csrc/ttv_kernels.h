@@ -26,6 +26,9 @@ int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t
 int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
                         int d, hipStream_t s);
 
+int64_t ttvk_mx_scale_ld(int d);     // bytes of E8M0 scales per row of width d
+int ttvk_quant_mx_fp8(const void* in, int in_dtype, int ld_in, void* out, int ld_out, void* mx, float* row_scales, int rows, int d, hipStream_t s);
+
 int ttvk_clip_from_u8(const void* frames, long long n_pix, void* clip, int dtype, hipStream_t s);
 
 // ---- ttv_gemm.hip ----
@@ -73,7 +76,9 @@ struct GemmArgs {
 };
 struct ClipPtrs { void* p[TTV_MAX_CLIPS_PER_LAUNCH]; };
 int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
-int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, const float* w_scale, hipStream_t s);
+// x_mx / w_mx: E8M0 block scales (ttvk_quant_mx_fp8's layout) - both or neither; with them the fp32 row factors are optional
+int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, const float* w_scale, hipStream_t s, const void* x_mx = nullptr,
+                  const void* w_mx = nullptr);
 bool ttvk_gemm_supports_resid_norm(int dtype, int N, int K);
 
 // ---- ttv_attn.hip ----
@@ -91,6 +96,7 @@ int64_t ttvk_vq_workspace_bytes(int rows);
 int ttvk_vq_l2_argmin(const void* z, int dtype, int ldz, const void* cb, int ldc, const float* cnorm, int rows, int N, int C, int* indices,
                       float* best_dist, void* workspace, int64_t workspace_bytes, hipStream_t s);
 int ttvk_vq_lookup(const void* cb, int dtype, int ldc, const int* indices, int rows, int C, void* codes, int ldo, hipStream_t s);
+int ttvk_vq_lookup_bwd(const void* dcodes, int dtype, int ld, const int* indices, int rows, int C, float* dcb, int ldc, hipStream_t s);
 
 // ---- ttv_mlp.hip ----
 bool ttvk_mlp_fused_supported(int dtype, int width, int inner);

@@ -90,7 +90,7 @@ static int check(const ttv_tower_dims* d, const ttv_batch* b) {
   TTV_CHECK_ARG(d->layers >= 1 && d->layers <= 64, "layers out of range");
   TTV_CHECK_ARG(d->head_dim == 64 && d->width == d->q_heads * 64 && d->width <= 1024, "width must be q_heads*64 <= 1024");
   TTV_CHECK_ARG(b->blocks64 && b->row_seq, "training needs batch.blocks64 and batch.row_seq");
-  TTV_CHECK_ARG(d->token_size >= 1 && d->token_size <= TTV_MAX_FSQ, "training towers take token_size <= %d (the wider tokens of the L2 quantiser are an inference path)", TTV_MAX_FSQ);
+  TTV_CHECK_ARG(d->token_size >= 1 && d->token_size <= TTV_MAX_TOKEN, "training towers take token_size <= %d", TTV_MAX_TOKEN);
   return TTV_OK;
 }
 

@@ -266,3 +266,24 @@ int ttvk_vq_lookup(const void* cb, int dtype, int ldc, const int* indices, int r
   TTV_CHECK_LAUNCH("vq_lookup");
   return TTV_OK;
 }
+
+// d codebook[idx[r], :] += d codes[r, :]: the gradient of the straight-through lookup codes = codebook[idx] with respect to the
+// codebook (fp32 accumulation; entries shared by several rows add up: float atomics, a few KB of traffic).
+template <typename T>
+__global__ __launch_bounds__(256) void k_vq_lookup_bwd(const T* __restrict__ dcodes, int ld, const int* __restrict__ indices, int rows, int C,
+                                                       float* __restrict__ dcb, int ldc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * C) return;
+  const int r = (int)(i / C), c = (int)(i % C);
+  atomicAdd(dcb + (size_t)indices[r] * ldc + c, Cvt<T>::to_f(dcodes[(size_t)r * ld + c]));
+}
+
+int ttvk_vq_lookup_bwd(const void* dcodes, int dtype, int ld, const int* indices, int rows, int C, float* dcb, int ldc, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(dtype == TTV_BF16 || dtype == TTV_F32, "vq_lookup_backward: bad dtype");
+  dim3 grid((unsigned)(((long)rows * C + 255) / 256));
+  if (dtype == TTV_F32) hipLaunchKernelGGL((k_vq_lookup_bwd<float>), grid, dim3(256), 0, s, (const float*)dcodes, ld, indices, rows, C, dcb, ldc);
+  else hipLaunchKernelGGL((k_vq_lookup_bwd<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dcodes, ld, indices, rows, C, dcb, ldc);
+  TTV_CHECK_LAUNCH("vq_lookup_bwd");
+  return TTV_OK;
+}

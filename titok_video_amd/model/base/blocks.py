@@ -135,7 +135,7 @@ class _Tower(nn.Module):
 
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
         params = self._param_list()
-        key = (dtype, str(device), _versions(params), bool(getattr(self, "fp8_linears", False)))
+        key = (dtype, str(device), _versions(params), str(getattr(self, "fp8_linears", False)))
         if _PACK_CHECK:
             key = key + (float(sum(p.detach().double().sum() for p in params)),)
         if self._pack is None or self._pack_key != key:
@@ -344,7 +344,31 @@ class _WeightPack:
             keep.append(t)
             return t.data_ptr()
 
-        use_f8 = bool(getattr(tower, "fp8_linears", False)) and dtype == torch.bfloat16 and not fold and tower.width % 128 == 0
+        f8_mode = getattr(tower, "fp8_linears", False)
+        use_f8 = bool(f8_mode) and dtype == torch.bfloat16 and not fold and tower.width % 128 == 0
+        # fp8_linears = "mx": all four linears of a layer in block-scaled (MX) e4m3, the pre-norm gains folded into the images
+        # (ttv_layer_weights.to_qkv_mx ...); True: round 2's row-scaled to_qkv / w12
+        use_mx = use_f8 and str(f8_mode).lower() == "mx" and tower.inner % 128 == 0
+        if use_mx and use_qs:
+            self.q_prescaled = 1          # the MX image of to_qkv carries the factor on its q rows
+
+        def f8_mx(w, g=None, q_rows=0):
+            """(e4m3 image, fp32 row factors, E8M0 block scales) of W' = w * gain[None, :] (q rows pre-scaled): ttv_quant_mx_fp8."""
+            if not use_mx:
+                return None, None, None
+            t = w.detach().to(device=device, dtype=torch.float32)
+            t = (t * g.detach().to(device=device, dtype=torch.float32)[None, :]) if g is not None else t.clone()
+            if q_rows and q_scale is not None:
+                t[:q_rows] *= q_scale
+            t = t.contiguous()
+            n_rows, k = t.shape
+            q = torch.empty((n_rows, k), dtype=torch.uint8, device=device)
+            sc = torch.empty(n_rows, dtype=torch.float32, device=device)
+            mx = torch.zeros((n_rows, int(_lib.lib().ttv_mx_scale_bytes_per_row(k))), dtype=torch.uint8, device=device)
+            _lib.check(_lib.lib().ttv_quant_mx_fp8(t.data_ptr(), _lib.TTV_F32, k, q.data_ptr(), k, mx.data_ptr(), sc.data_ptr(), n_rows, k,
+                                                   _lib.stream_ptr(device)), "ttv_quant_mx_fp8")
+            keep.extend([t, q, sc, mx])
+            return q.data_ptr(), sc.data_ptr(), mx.data_ptr()
 
         def f8_rows(w, q_rows=0):
             """(pointer to e4m3 [N, K], pointer to fp32 row scales) of a linear weight for the mixed bf16 / fp8 path; the q rows carry
@@ -412,10 +436,19 @@ class _WeightPack:
             a, f = ml.attn_layer[i], ml.ffd_layer[i]
             pack_ptr, pack_rows = mlp_packed(f.w12.weight, f.norm.weight, f.w3.weight, a.out_proj.weight,
                                              ml.attn_layer[i + 1] if i + 1 < n else None)
-            qkv8, qkv8s = f8_rows(a.to_qkv.weight, q_rows=tower.width)
-            w128, w128s = f8_rows(f.w12.weight)
+            if use_mx:
+                qkv8, qkv8s, qkvmx = f8_mx(a.to_qkv.weight, a.pre_ln.weight, q_rows=tower.width)
+                w128, w128s, w12mx = f8_mx(f.w12.weight, f.norm.weight)
+                wo8, wo8s, womx = f8_mx(a.out_proj.weight)
+                w38, w38s, w3mx = f8_mx(f.w3.weight)
+            else:
+                qkv8, qkv8s = f8_rows(a.to_qkv.weight, q_rows=tower.width)
+                w128, w128s = f8_rows(f.w12.weight)
+                qkvmx = w12mx = wo8 = wo8s = womx = w38 = w38s = w3mx = None
             self.layers[i] = _lib.LayerWeights(
                 to_qkv_f8=qkv8, to_qkv_f8_scale=qkv8s, w12_f8=w128, w12_f8_scale=w128s,
+                to_qkv_mx=qkvmx, w12_mx=w12mx, out_proj_f8=wo8, out_proj_f8_scale=wo8s, out_proj_mx=womx,
+                w3_f8=w38, w3_f8_scale=w38s, w3_mx=w3mx,
                 pre_ln=gain(a.pre_ln.weight), to_qkv=lin(a.to_qkv.weight), out_proj=lin(a.out_proj.weight),
                 ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,

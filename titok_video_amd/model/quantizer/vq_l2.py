@@ -71,7 +71,33 @@ class L2Quantizer(nn.Module):
         return out
 
     def forward(self, z: torch.Tensor):
+        """Straight-through quantiser: VALUE codebook[idx]; gradient identity towards z (the reference's FSQ estimator, fsq.py:48-51)
+        and, through the lookup, towards the codebook rows that were selected (scatter-add of the decoder's token gradient:
+        `_LookupFn`) - the one quantiser slot of the reference is trained end to end by the reconstruction loss (titok.py:37,47-52,
+        train.py:65-83); any commitment / codebook loss is the caller's to add."""
         idx = self.indices(z.detach())
-        q = self.lookup(idx, z.dtype)
-        codes = z + (q - z).detach() if z.requires_grad else q        # straight-through estimator
+        if torch.is_grad_enabled() and (z.requires_grad or self.codebook.requires_grad):
+            q = _LookupFn.apply(self, idx, z.dtype, self.codebook)
+            codes = q + (z - z.detach()) if z.requires_grad else q
+        else:
+            codes = self.lookup(idx, z.dtype)
         return codes, {"indices": idx}
+
+
+class _LookupFn(torch.autograd.Function):
+    """codes = codebook[idx] on the HIP path; backward = ttv_vq_lookup_backward (fp32 scatter-add into the codebook gradient)."""
+
+    @staticmethod
+    def forward(ctx, vq: "L2Quantizer", idx: torch.Tensor, dtype, codebook: torch.Tensor):
+        ctx.idx, ctx.shape, ctx.cb_dtype = idx, tuple(codebook.shape), codebook.dtype
+        return vq.lookup(idx, dtype)
+
+    @staticmethod
+    def backward(ctx, dcodes):
+        dcodes = dcodes.contiguous()
+        if dcodes.dtype not in (torch.float32, torch.bfloat16):
+            dcodes = dcodes.float()
+        dcb = torch.zeros(ctx.shape, dtype=torch.float32, device=dcodes.device)
+        _lib.check(_lib.lib().ttv_vq_lookup_backward(dcodes.data_ptr(), _lib.dtype_code(dcodes.dtype), dcodes.shape[1], ctx.idx.data_ptr(), dcodes.shape[0],
+                                                     dcodes.shape[1], dcb.data_ptr(), ctx.shape[1], _lib.stream_ptr(dcodes.device)), "ttv_vq_lookup_backward")
+        return None, None, None, dcb.to(ctx.cb_dtype)

@@ -10,7 +10,8 @@ types and state-dict keys (`encoder.*`, `decoder.*`; FSQ has no persistent keys)
   * BUILD-DEFINED, NOT REFERENCE-PINNED: `config.tokenizer.model.quantizer = "l2"` (with `codebook_size`, `token_size`) wires the
     nearest-codebook-entry quantiser of BASELINE.json's configs #4 / #5 (8192 x 32, 16384 x 64) into the one quantiser slot the
     reference has (titok.py:37,47-52): encode -> L2 argmin + straight-through lookup -> decode.  The reference itself ships FSQ only;
-    the default (`quantizer` absent or "fsq") is the reference's model.  Inference only (the training towers take FSQ-sized tokens).
+    the default (`quantizer` absent or "fsq") is the reference's model.  Trainable (round 4): under autograd the towers record their
+    tape, the lookup is straight-through towards the encoder and passes the decoder's token gradient to the selected codebook rows.
 """
 from __future__ import annotations
 
@@ -65,7 +66,13 @@ class TiTok(nn.Module):
         counts = host_ints(token_counts)
         if self.quantizer_kind == "l2":
             if self.encoder._wants_grad(*x):
-                raise NotImplementedError("the L2-quantiser wiring is an inference path (the training towers take token_size <= 8)")
+                # training through the one quantiser slot (titok.py:47-52, train.py:65-83): tape-recording towers, straight-through lookup
+                z = self.encoder.forward_z(x, counts, grids)                          # fp32, carries the autograd graph
+                codes, info = self.quantize(z.to(x[0].dtype))
+                self.last_bounded = None
+                if split_indices:
+                    info["indices"] = torch.split(info["indices"], counts, dim=0)
+                return codes, info
             z = self.encoder.run(x, counts, grids, None, want_z=True)["z"]          # fp32 [sum K, token_size]
             codes, info = self.quantize(z.to(x[0].dtype))
             self.last_bounded = None
