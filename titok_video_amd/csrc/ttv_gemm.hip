@@ -826,11 +826,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16_t256(GemmDev p, int n_ftil
 typedef int v8i32 __attribute__((ext_vector_type(8)));
 
 // MX = true (round 4): both operands carry one E8M0 scale per 32 CONSECUTIVE k elements (k_quant_mx_fp8), fed to the instruction's
-// per-lane scale operands: lane group kq then has to hold k = 32 kq .. 32 kq + 31 of the 128-element tile, so the LDS-DMA source side
-// places source chunk 2c at image chunk c and 2c + 1 at c + 4 (the reads stay chunk kq and kq + 4: the conflict-free pattern); a
-// lane's scale bytes of four consecutive k-tiles arrive as one dword per operand row (prefetched one group ahead) and are shifted
-// into byte 0.  The per-row fp32 factors become optional (activations: the rstd of the folded pre-norm, p.x_scale; weights: the
-// row factor of the pack).
+// per-lane scale operands.  Measured on the part (tools/ubench/mx_probe.hip, profiles/r04_mx_probe.txt): the instruction's k order is
+// "lane group g holds bytes 16 g .. 16 g + 15 and 64 + 16 g .. 64 + 16 g + 15 of the 128-byte row" - exactly the chunk pair (kq, kq + 4)
+// this kernel reads - and the scale byte of lane (row, group b) multiplies k-block b = bytes 32 b .. 32 b + 31 of that row (the low
+// halves of groups 2b', 2b'+1 for b < 2, the high halves for b >= 2), NOT the 32 bytes the lane itself holds; op_sel picks the byte.
+// So the operand image stays as it is and lane (row, kq) supplies the scale of block 4 kt + kq: a lane's scale bytes of four
+// consecutive k-tiles arrive as one dword per operand row (prefetched one group ahead) and are shifted into byte 0.  The per-row
+// fp32 factors become optional (activations: the rstd of the folded pre-norm, p.x_scale; weights: the row factor of the pack).
 template <int EPI, int NJ, bool MX = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
@@ -857,16 +859,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
     if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
     else wr = fbase + row;
     wr = wr < p.w_rows ? wr : p.w_rows - 1;
-    const int ch = lp ^ ((row >> 1) & 7);
-    woff[i] = (uint32_t)wr * (uint32_t)p.ldw + (uint32_t)((MX ? ((ch & 3) * 2 + (ch >> 2)) : ch) * 16);
+    woff[i] = (uint32_t)wr * (uint32_t)p.ldw + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
   }
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int row = wave * (8 * XI) + i * 8 + lr;
     int xr = tbase + row;
     xr = xr < p.M ? xr : p.M - 1;
-    const int ch = lp ^ ((row >> 1) & 7);
-    xoff[i] = (uint32_t)xr * (uint32_t)p.ldx + (uint32_t)((MX ? ((ch & 3) * 2 + (ch >> 2)) : ch) * 16);
+    xoff[i] = (uint32_t)xr * (uint32_t)p.ldx + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&lds[0][0];
   constexpr uint32_t BUFB = (TF + TTK) * 128;

@@ -51,6 +51,14 @@ class TiTok(nn.Module):
             setattr(self, name, mod)
         self.apply(init_weights)                       # nn.Linear / RMSNorm only: the L2 codebook keeps its start values
         self.last_bounded = None   # fp32 FSQ pre-rounding values of the last encode(want_bounded=True)
+        # Index-exact inference (round 4): token indices are decided by the ENCODER alone (fsq.py:123-135 forces fp32 inside FSQ because
+        # round() is discontinuous), so `encoder_dtype = torch.float32` runs the encoder on the exact-fp32 MFMA kernels - the reference's
+        # fp32 indices bit for bit - whatever dtype the clips arrive in, while the decoder keeps computing in the clips' dtype (bf16).
+        # `decoder_dtype` likewise fixes the decoder's compute dtype (its reconstructions come back in that dtype).  With fp32 master
+        # parameters, `encoder_dtype = float32, decoder_dtype = bfloat16` is the index-exact configuration bench.py times as `exact_index`.
+        # None (default): both towers follow the clips, as the reference's modules do.
+        self.encoder_dtype = None
+        self.decoder_dtype = None
 
     # ---- encode ---------------------------------------------------------------------------------------------------------
     def _encode_differentiable(self, clips, counts, grids, split_indices):
@@ -64,6 +72,10 @@ class TiTok(nn.Module):
 
     def encode(self, x, token_counts, grids=None, split_indices=False, want_bounded=False):
         counts = host_ints(token_counts)
+        if self.encoder_dtype is not None and x[0].dtype != self.encoder_dtype and not self.encoder._wants_grad(*x):
+            out_dtype = x[0].dtype
+            codes, info = self.encode([c.to(self.encoder_dtype) for c in x], counts, grids, split_indices, want_bounded)
+            return codes.to(out_dtype), info
         if self.quantizer_kind == "l2":
             if self.encoder._wants_grad(*x):
                 # training through the one quantiser slot (titok.py:47-52, train.py:65-83): tape-recording towers, straight-through lookup
@@ -88,6 +100,8 @@ class TiTok(nn.Module):
 
     # ---- decode ---------------------------------------------------------------------------------------------------------
     def decode(self, x, token_counts, grids):
+        if self.decoder_dtype is not None and x.dtype != self.decoder_dtype and not self.decoder._wants_grad(x):
+            x = x.to(self.decoder_dtype)
         return self.decoder(x, token_counts, grids)
 
     def decode_indices(self, indices, grids, token_counts=None):
