@@ -93,6 +93,15 @@ int ttv_quant_rows_fp8(const void* in, int dtype, int ld_in, const float* gain, 
 int ttv_linear_fp8(const void* xq, int ldx, const float* x_scale, const void* wq, int ldw, const float* w_scale, void* y, int ldy, int M, int N,
                    int K, int epilogue, const float* rope_cs, int d_model, int gqa_dim, void* stream);
 
+/* Split image of an fp32 matrix [rows, K] (K % 4 == 0) for the three-pass bf16 linears (ttv_tower_weights.f32_split3): for every aligned
+ * group of four k values the 16 bytes (hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3) with hi = bf16(x), lo = bf16(x - hi) (round to nearest even).
+ * out has the size and leading dimension (in fp32 elements) of the input.  The image is what k_gemm_f32<.., SPLIT> stages with the copies
+ * of the fp32 kernel; no reference counterpart (the reference computes in the parameter dtype, titok.py:61). */
+int ttv_split3_pack(const float* w, int ldw, void* out, int ldo, int rows, int K, void* stream);
+/* y[M,N] fp32 = x[M,K] fp32 @ W^T (+ bias fp32) with W given as its split image: the three-pass bf16 linear on its own (tests; the towers
+ * reach the same kernel with their own epilogues).  Replaces nn.Linear (blocks.py:49,93; transformer.py:73-76) in the split-bf16 mode. */
+int ttv_linear_split3(const float* x, int ldx, const void* w_image, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, void* stream);
+
 /* Block-scaled (OCP MX) e4m3 quantisation of rows [rows, width] (dtype bf16 / fp32, width % 128 == 0): q[r, k] = round_e4m3(y / 2^E),
  * one E8M0 byte E + 127 per 32 consecutive k, E = ceil(log2(max|block| / 448)); with row_scales != NULL (weights) y = in / row_scales[r],
  * row_scales[r] = max|row| / 448, else y = in.  mx: ttv_mx_scale_bytes_per_row(width) bytes per row, block b = k / 32 at byte
@@ -198,6 +207,8 @@ int ttv_decoder_embed(const void* codes, int token_size, const void* w, const vo
 #define TTV_ATTN_ALLFULL 8   /* the table holds full items only (mode 0 everywhere, padding entries allowed) */
 #define TTV_ATTN_PIPE 16     /* bf16, with TTV_ATTN_QSCALED | TTV_ATTN_ALLFULL and no tape: run the software-pipelined kernel (opt-in: measured
                                 slower than the plain loop, see ttv_attn.hip; the towers set it under the environment switch TTV_ATTN_PIPE=1) */
+#define TTV_ATTN_SPLIT3 32   /* fp32: the split-bf16 ("three-pass") kernel - operands hi + lo in bf16, three bf16 MFMA passes per product, fp32
+                                softmax and accumulation (~2^-17 relative per product); the towers set it with ttv_tower_weights.f32_split3 */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 /* The same operator (transformer.py:100,103) on the 64-query-rows-per-wave kernel: bf16, head_dim 64, q pre-scaled (flags must carry
@@ -288,6 +299,12 @@ typedef struct ttv_tower_weights {
   /* optional (decoder, bf16, width 256): proj_out_w * ln_post gain[None,:]; when non-NULL the ln_post RMSNorm runs inside the
    * proj_out GEMM (rows gathered through patch_rows, rstd from the register-resident row) */
   const void* proj_out_pn;
+  /* fp32 towers, inference: 1 = "split-bf16" arithmetic (round 4).  proj_in_w and the layers' to_qkv / out_proj / w12 / w3 then point at
+   * SPLIT IMAGES made by ttv_split3_pack (same bytes and leading dimension as the fp32 matrix), every linear runs as three bf16 MFMA
+   * passes on hi + lo operands (fp32 accumulation) and the attention kernel with TTV_ATTN_SPLIT3; norms, rotary, softmax, GELU, the
+   * residual stream, the encoder tail and FSQ stay exact fp32.  Measured: every token index of the reference's fp32 run is kept on the
+   * benchmark fixture (max |pre-rounding FSQ value error| ~6e-4) at about a third of the exact-fp32 MFMA kernels' time. */
+  int32_t f32_split3;
 } ttv_tower_weights;
 
 /* Per-batch metadata, built on the host from Python ints (replaces the device-side bookkeeping and its

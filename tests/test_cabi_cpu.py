@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.FsqParams) == 4 + 6 * 4 * _lib.TTV_MAX_FSQ
     assert C.sizeof(_lib.TowerDims) == 15 * 4
     assert C.sizeof(_lib.LayerWeights) == 25 * 8   # 24 pointers (8 of them the MX fp8 images, round 4) + int32 mlp_pack_qkv_rows + int32 qkv_q_prescaled
-    assert C.sizeof(_lib.TowerWeights) == 10 * 8
+    assert C.sizeof(_lib.TowerWeights) == 11 * 8   # 10 pointers + int32 f32_split3 (padded)
     # + blocks64, row_seq, n_blocks64, qblocks_paired, qblocks_all_full (+ pad), items64, n_items64 (+ pad), rope_ids, rope_base
     assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 16 + 8 + 8 + 16
     src = open(HEADER).read()

@@ -50,7 +50,8 @@ class LayerWeights(C.Structure):
 
 class TowerWeights(C.Structure):
     _fields_ = [("proj_in_w", vp), ("proj_in_b", vp), ("mask_token", vp), ("ln_pre_t", vp), ("ln_pre_p", vp),
-                ("ln_post", vp), ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerWeights)), ("proj_out_pn", vp)]
+                ("ln_post", vp), ("proj_out_w", vp), ("proj_out_b", vp), ("layers", C.POINTER(LayerWeights)), ("proj_out_pn", vp),
+                ("f32_split3", i32)]
 
 
 class Batch(C.Structure):
@@ -95,6 +96,8 @@ SYMBOLS = {
     "ttv_vq_lookup_backward": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ttv_quant_rows_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, f32, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "ttv_linear_fp8": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "ttv_split3_pack": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "ttv_linear_split3": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ttv_mx_scale_bytes_per_row": (C.c_int64, [C.c_int]),
     "ttv_quant_mx_fp8": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "ttv_linear_fp8_mx": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,

@@ -134,6 +134,7 @@ static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, co
 // One ResidualAttentionBlock stack (reference transformer.py:126-146) on ws.x in place.
 static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const TowerWs& ws, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
+  const int split3 = (dt == TTV_F32 && w->f32_split3) ? 1 : 0;       // fp32 towers on the three-pass bf16 kernels (ttv_tower_weights.f32_split3)
   const int nq = 2 * dm + 2 * g;
   bool qkv_ready = false;   // the previous layer's tail kernel already produced this layer's rotated qkv
   bool rstd_valid = false;  // ws.rstd holds rsqrt(mean(x^2) + eps) of the current ws.x (written by the kernel that produced x)
@@ -168,7 +169,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       if (fold_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
       if (!fold_qkv && !fold_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
       GemmArgs a = {};
-      a.dtype = dt;
+      a.dtype = dt; a.split3 = split3;
       a.prenorm = fold_qkv; a.eps = d->eps;
       a.row_scale = fold_gen ? ws.rstd : nullptr;
       const void* w_plain = (dt == TTV_BF16 && lw.to_qkv_qs) ? lw.to_qkv_qs : lw.to_qkv;   // inference copy with scaled q rows, if packed
@@ -187,7 +188,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     else
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
-                               (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
+                               (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0), dt, s));
     // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h).
     // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
     // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs
@@ -207,7 +208,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       continue;
     }
     GemmArgs o = {};
-    o.dtype = dt;
+    o.dtype = dt; o.split3 = split3;
     o.x = ws.ao; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
     if (i == 0) {
       o.alpha = 1.f; o.y = ws.x; o.ldy = dm;
@@ -246,7 +247,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     if (fold_ffd_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
     if (!fold_ffd && !fold_ffd_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
-    f.dtype = dt;
+    f.dtype = dt; f.split3 = split3;
     f.prenorm = fold_ffd; f.eps = d->eps;
     f.row_scale = fold_ffd_gen ? ws.rstd : nullptr;
     f.x = (fold_ffd || fold_ffd_gen) ? ws.x : ws.xn; f.ldx = dm; f.w = (fold_ffd || fold_ffd_gen) ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
@@ -254,7 +255,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     }
     rstd_valid = false;
     GemmArgs f3 = {};
-    f3.dtype = dt;
+    f3.dtype = dt; f3.split3 = split3;
     f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = L; f3.N = dm; f3.K = d->inner; f3.resid = ws.x; f3.ldr = dm;
     if (i == 0) {
       f3.alpha = 1.f; f3.y = ws.x; f3.ldy = dm;
@@ -325,6 +326,18 @@ int ttv_quant_rows_fp8(const void* in, int dtype, int ld_in, const float* gain, 
                        int width, void* stream) {
   TTV_CHECK_ARG(rows == 0 || (in && out && scales), "quant_rows_fp8: null buffer");
   return ttvk_quant_rows_fp8(in, dtype, ld_in, gain, eps, out, ld_out, scales, rows, width, (hipStream_t)stream);
+}
+
+int ttv_split3_pack(const float* w, int ldw, void* out, int ldo, int rows, int K, void* stream) {
+  TTV_CHECK_ARG(rows == 0 || (w && out), "split3_pack: null buffer");
+  return ttvk_split3_pack(w, ldw, out, ldo, rows, K, (hipStream_t)stream);
+}
+
+int ttv_linear_split3(const float* x, int ldx, const void* w_image, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, void* stream) {
+  TTV_CHECK_ARG(M == 0 || (x && w_image && y), "linear_split3: null buffer");
+  GemmArgs a = {};
+  a.dtype = TTV_F32; a.split3 = 1; a.x = x; a.ldx = ldx; a.w = w_image; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.y = y; a.ldy = ldy; a.bias = bias;
+  return ttvk_gemm(EPI_STORE, a, (hipStream_t)stream);
 }
 
 int64_t ttv_mx_scale_bytes_per_row(int width) { return ttvk_mx_scale_ld(width); }
@@ -527,6 +540,7 @@ int ttv_encoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
   GemmArgs a = {};
   a.dtype = dt; a.x = ws.pa; a.ldx = pd; a.w = w->proj_in_w; a.ldw = pd; a.M = P; a.N = dm; a.K = pd; a.y = ws.pb; a.ldy = dm;
   a.bias = w->proj_in_b; a.add_scalar = w->mask_token;
+  a.split3 = (dt == TTV_F32 && w->f32_split3) ? 1 : 0;
   if (gather) {
     a.gather = 1; a.clips = (void* const*)clips; a.n_clips = b->n_clips; a.clip_desc = b->clip_desc; a.patch_rows = b->patch_rows;
     a.row_seq = b->row_seq; a.patch_t = d->patch_t; a.patch_h = d->patch_h; a.patch_w = d->patch_w;
@@ -563,6 +577,7 @@ int ttv_decoder_forward(const ttv_tower_dims* d, const ttv_tower_weights* w, con
   // patches = proj_out(ln_post(x[patch rows])) -> unpatchify (blocks.py:171-176)
   GemmArgs a = {};
   a.dtype = dt; a.w = w->proj_out_w; a.ldw = dm; a.M = P; a.N = pd; a.K = dm; a.y = ws.pa; a.ldy = pd; a.ldx = dm;
+  a.split3 = (dt == TTV_F32 && w->f32_split3) ? 1 : 0;
   a.bias = w->proj_out_b;
   if (dt == TTV_BF16 && dm == 256 && w->proj_out_pn && pd % 8 == 0) {
     // ln_post folded into the GEMM: gain in the weight columns, rstd from the register-resident row, rows gathered in place

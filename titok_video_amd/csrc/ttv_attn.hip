@@ -1221,6 +1221,227 @@ __global__ __launch_bounds__(256, 2) void k_attn_f32(const float* __restrict__ q
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 ("three-pass") attention for fp32 towers (flag TTV_ATTN_SPLIT3; round 4).  fp32 in, fp32 out, fp32 softmax - as k_attn_f32 -
+// but both products run on the bf16 matrix pipe with every operand split into hi + lo (hi = bf16(x), lo = bf16(x - hi)):
+//     S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T        O^T += Vh^T Ph^T + Vh^T Pl^T + Vl^T Ph^T        (fp32 accumulation)
+// ~2^-17 relative per product instead of bf16's 2^-9: with the split GEMMs (k_gemm_f32<.., SPLIT>) the encoder keeps every token index
+// of the reference's fp32 run on the benchmark fixture at about a third of the exact-fp32 kernels' time (tests/probes/split_bf16_probe.py,
+// bench.py `exact_index`).  Structure: k_attn_bf16's tiles and fragment reads (K rows XOR-swizzled for ds_read_b128, V^T through
+// ds_read_b64_tr_b16) on FOUR bf16 tiles - K hi / lo, V hi / lo - filled by register staging: a thread loads 16 bytes of fp32, splits
+// them and stores the two 8-byte halves (the next tile's loads are in flight behind the MFMAs).  Exact running maximum, exact row sums
+// of the fp32 p (only the operands of the two products are split).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split4_f32(const uint4 v, uint2& hi, uint2& lo) {
+  const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+  const bf16_t h0 = (bf16_t)x0, h1 = (bf16_t)x1, h2 = (bf16_t)x2, h3 = (bf16_t)x3;
+  const bf16x4 hv = {h0, h1, h2, h3};
+  const bf16x4 lv = {(bf16_t)(x0 - (float)h0), (bf16_t)(x1 - (float)h1), (bf16_t)(x2 - (float)h2), (bf16_t)(x3 - (float)h3)};
+  hi = __builtin_bit_cast(uint2, hv);
+  lo = __builtin_bit_cast(uint2, lv);
+}
+
+template <bool GATE>
+__global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
+                                                        const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
+                                                        int rep, float c_exp /* scale * log2(e) */) {
+  __shared__ __attribute__((aligned(16))) uint4 tiles[4][KB * 8];      // K hi, K lo, V hi, V lo: 64 keys x 128 bytes each
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int seq = qblocks[4 * blockIdx.x], q0 = qblocks[4 * blockIdx.x + 1], head = qblocks[4 * blockIdx.x + 2];
+  const int mode = qblocks[4 * blockIdx.x + 3];
+  if (seq < 0) return;
+  const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  const int q_lim = (mode && q0 + 64 < S) ? q0 + 64 : S;      // half item: 64 query rows, waves 0 and 1 over the whole key range
+  const bool wave_live = !(mode && wave >= 2);                 // its waves 2, 3 only help staging
+  const int kvh = head / rep;
+  const float* qbase = qkvg + (size_t)s0 * ld + head * 64;
+  const float* gbase = qkvg + (size_t)s0 * ld + d_model + head * 64;
+  const float* kbase = qkvg + (size_t)s0 * ld + 2 * d_model + kvh * 64;
+  const float* vbase = kbase + gqa;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[query r][16 ks + 8 h + 0..7], split once
+  const int qrow = q0 + wave * 32 + r;
+  const int qrc = qrow < S ? qrow : S - 1;
+  bf16x8 qh[4], ql[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint4 a = *reinterpret_cast<const uint4*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8);
+    const uint4 b = *reinterpret_cast<const uint4*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8 + 4);
+    uint2 ah, al, bh, bl;
+    split4_f32(a, ah, al);
+    split4_f32(b, bh, bl);
+    qh[ks] = __builtin_bit_cast(bf16x8, make_uint4(ah.x, ah.y, bh.x, bh.y));
+    ql[ks] = __builtin_bit_cast(bf16x8, make_uint4(al.x, al.y, bl.x, bl.y));
+  }
+
+  // staging: a tile is 64 keys x 16 float chunks; thread t takes float chunk t & 15 (dims 4 sch .. 4 sch + 3) of keys (t >> 4) + 16 i
+  const int skey = tid >> 4, sch = tid & 15;
+  uint4 sk[4], sv[4];
+#define S3_GLOAD(kt_)                                                                      \
+  do {                                                                                     \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                  \
+      int k__ = (kt_) * KB + skey + 16 * i__;                                              \
+      k__ = k__ < S ? k__ : S - 1;                                                         \
+      sk[i__] = *reinterpret_cast<const uint4*>(kbase + (size_t)k__ * ld + sch * 4);       \
+      sv[i__] = *reinterpret_cast<const uint4*>(vbase + (size_t)k__ * ld + sch * 4);       \
+    }                                                                                      \
+  } while (0)
+  // bf16 tile row = 128 bytes = 8 chunks of 16 bytes; float chunk sch is the 8-byte half sch & 1 of chunk sch >> 1, stored at the
+  // swizzled chunk position k_attn_bf16's fragment reads expect: K: c ^ ((row >> 1) & 7), V: c ^ (((row >> 1) & 1) << 2).
+  // Rows skey + 16 i: (row >> 1) & 7 and (row >> 1) & 1 do not depend on i.
+  char* const tk_h = reinterpret_cast<char*>(&tiles[0][0]);
+  char* const tk_l = reinterpret_cast<char*>(&tiles[1][0]);
+  char* const tv_h = reinterpret_cast<char*>(&tiles[2][0]);
+  char* const tv_l = reinterpret_cast<char*>(&tiles[3][0]);
+  const int kst = skey * 128 + (((sch >> 1) ^ ((skey >> 1) & 7)) << 4) + (sch & 1) * 8;
+  const int vst = skey * 128 + (((sch >> 1) ^ (((skey >> 1) & 1) << 2)) << 4) + (sch & 1) * 8;
+#define S3_LSTORE()                                                                        \
+  do {                                                                                     \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                  \
+      uint2 hi__, lo__;                                                                    \
+      split4_f32(sk[i__], hi__, lo__);                                                     \
+      *reinterpret_cast<uint2*>(tk_h + kst + i__ * 2048) = hi__;                           \
+      *reinterpret_cast<uint2*>(tk_l + kst + i__ * 2048) = lo__;                           \
+      split4_f32(sv[i__], hi__, lo__);                                                     \
+      *reinterpret_cast<uint2*>(tv_h + vst + i__ * 2048) = hi__;                           \
+      *reinterpret_cast<uint2*>(tv_l + vst + i__ * 2048) = lo__;                           \
+    }                                                                                      \
+  } while (0)
+
+  // fragment offsets exactly as in k_attn_bf16
+  const int ksw = (r >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((ks * 2 + h) ^ ksw) << 4);
+  const int gi = lane & 15, tq = gi >> 2, tp = gi & 3, g16 = (lane >> 4) & 1;
+  const int vsw = (tq >> 1) & 1;
+  const int vlane = (4 * h + tq) * 128 + (g16 * 2 + (tp >> 1)) * 16 + (tp & 1) * 8;
+  const int voff_d0 = vlane + (vsw ? 64 : 0), voff_d1 = vlane + (vsw ? 0 : 64);
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (S + KB - 1) / KB;
+  S3_GLOAD(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();            // every wave is done with the previous tile
+    S3_LSTORE();
+    __syncthreads();
+    if (kt + 1 < nkt) S3_GLOAD(kt + 1);   // in flight behind this tile's MFMAs
+    if (!wave_live) continue;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {          // two 32-key sub-tiles
+      if (kt * KB + t * 32 >= S) break;    // wave-uniform
+      // ---- S^T = K Q^T, three passes (cross terms first) ----
+      f32x16 sc = zero16;
+      {
+        bf16x8 kfh[4], kfl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          kfh[ks] = *reinterpret_cast<const bf16x8*>(tk_h + koff[ks] + t * 4096);
+          kfl[ks] = *reinterpret_cast<const bf16x8*>(tk_l + koff[ks] + t * 4096);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[ks], qh[ks], sc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[ks], ql[ks], sc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[ks], qh[ks], sc, 0, 0, 0);
+      }
+      if (kt * KB + t * 32 + 32 > S) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kk = kt * KB + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (kk >= S) sc[e] = -INFINITY;
+        }
+      }
+      // ---- online softmax (fp32, exact running maximum) ----
+      float mx = sc[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mc = m_new * c_exp;
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        sc[e] = __builtin_amdgcn_exp2f(fmaf(sc[e], c_exp, -mc));
+        psum += sc[e];
+      }
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+        m_run = m_new;
+      }
+      l_run += psum;
+      // ---- P split into bf16 B-operand fragments: k-step sp = registers 8 sp .. 8 sp + 7 ----
+      bf16x8 ph[2], pl[2];
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16_t hv = (bf16_t)sc[8 * sp + j];
+          ph[sp][j] = hv;
+          pl[sp][j] = (bf16_t)(sc[8 * sp + j] - (float)hv);
+        }
+      // ---- O^T += V^T P^T, three passes ----
+#define S3_VFRAG(base_, dt_, sp_)                                                                                  \
+  ({                                                                                                               \
+    const char* vb__ = (base_) + ((dt_) == 0 ? voff_d0 : voff_d1) + t * 4096 + (sp_) * 2048;                       \
+    const bf16x4 lo__ = lds_read_tr16(vb__), hi__ = lds_read_tr16(vb__ + 1024);                                    \
+    (bf16x8){lo__[0], lo__[1], lo__[2], lo__[3], hi__[0], hi__[1], hi__[2], hi__[3]};                              \
+  })
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 vh0 = S3_VFRAG(tv_h, dt, 0), vh1 = S3_VFRAG(tv_h, dt, 1);
+        const bf16x8 vl0 = S3_VFRAG(tv_l, dt, 0), vl1 = S3_VFRAG(tv_l, dt, 1);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0, ph[0], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1, ph[1], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0, pl[0], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1, pl[1], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0, ph[0], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1, ph[1], o_acc[dt], 0, 0, 0);
+      }
+#undef S3_VFRAG
+    }
+  }
+#undef S3_GLOAD
+#undef S3_LSTORE
+  if (!wave_live) return;
+
+  // ---- normalise, gate, store (fp32, exact division and sigmoid as k_attn_f32): lane holds O[query r][32 dt + 8 g + 4 h + 0..3] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (qrow < q_lim) {
+    float* orow = out + (size_t)(s0 + qrow) * ldo + head * 64;
+    const float* grow = gbase + (size_t)qrow * ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        f32x4 v = {o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+        if (GATE) {
+          const f32x4 gt = *reinterpret_cast<const f32x4*>(grow + d0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= 1.0f / (1.0f + expf(-gt[e]));
+        }
+        *reinterpret_cast<f32x4*>(orow + d0) = v;
+      }
+  }
+}
+
 // flags: bit 0 (TTV_ATTN_GATE) multiply by sigmoid(gate); bit 1 (TTV_ATTN_PAIRED) the table is paired (see k_attn_bf16, NE = 2)
 // out_raw (bf16 only, with TTV_ATTN_GATE; leading dimension ldo): additionally receives the UNGATED attention output
 int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
@@ -1274,7 +1495,11 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
 #undef ATTN_LAUNCH
   } else if (dtype == TTV_F32) {
     const float c_exp = scale * 1.44269504088896340736f;
-    if (gate_mul)
+    if (flags & TTV_ATTN_SPLIT3) {
+      TTV_CHECK_ARG(!lse_out, "attention: the split-bf16 kernel is an inference path (no tape outputs)");
+      if (gate_mul) hipLaunchKernelGGL((k_attn_split3<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
+      else hipLaunchKernelGGL((k_attn_split3<false>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
+    } else if (gate_mul)
       hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
     else
       hipLaunchKernelGGL((k_attn_f32<false>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);

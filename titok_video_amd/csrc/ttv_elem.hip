@@ -182,6 +182,34 @@ int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* ga
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split image of an fp32 weight matrix for the three-pass bf16 linears (k_gemm_f32<.., SPLIT>): per aligned group of four k values the
+// 16 bytes (hi0..3 | lo0..3), hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  One thread per group.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split3_pack(const float* __restrict__ w, int ldw, uint4* __restrict__ out, int ldo4, int rows, int k4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * k4) return;
+  const int r = (int)(i / k4), c = (int)(i % k4);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)r * ldw + c * 4);
+  bf16x4 hv, lv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hv[e] = (bf16_t)v[e];
+    lv[e] = (bf16_t)(v[e] - (float)hv[e]);
+  }
+  const uint2 hp = __builtin_bit_cast(uint2, hv), lp = __builtin_bit_cast(uint2, lv);
+  out[(size_t)r * ldo4 + c] = make_uint4(hp.x, hp.y, lp.x, lp.y);
+}
+
+int ttvk_split3_pack(const float* w, int ldw, void* out, int ldo, int rows, int K, hipStream_t s) {
+  if (rows == 0) return TTV_OK;
+  TTV_CHECK_ARG(K > 0 && K % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)out % 16 == 0, "split3_pack: K and leading dims must be multiples of 4, pointers 16-byte aligned");
+  const long n = (long)rows * (K / 4);
+  hipLaunchKernelGGL(k_split3_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, ldw, (uint4*)out, ldo / 4, rows, K / 4);
+  TTV_CHECK_LAUNCH("split3_pack");
+  return TTV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // MX (OCP microscaling) e4m3 quantisation for the block-scaled fp8 linears (BASELINE config #5): every 32 consecutive elements of a
 // row share one E8M0 scale 2^E, E = ceil(log2(max|block| / 448)) (the smallest power of two that brings the block into e4m3's range);
 // q = round_e4m3(y / 2^E).  The scale bytes are what v_mfma_scale_f32_16x16x128_f8f6f4 takes as its per-lane scale operand

@@ -43,6 +43,7 @@ struct GemmDev {
   const float* row_scale;   // optional [M]: acc rows are multiplied by it first (folded pre-norm of the generic-K kernels)
   const int* rope_ids; const float* rope_base;   // optional: rotary factors by position id (k256 QKV kernel; see ttv_batch.rope_ids)
   const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma; either may be NULL with MX)
+  int split3;                                   // fp32 kernel: w is the split-bf16 image (hi | lo per 16-byte chunk), products in three bf16 passes
   const uint8_t* x_mx; const uint8_t* w_mx;     // MX block scales (E8M0, k_quant_mx_fp8's layout), ld_mx bytes per row
   int ld_mx;
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
@@ -1525,7 +1526,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
 #define F_TT 128
 #define F_BK 32
 
-template <int EPI>
+// SPLIT (round 4; "index-exact at a third of the bf16 rate"): the same tiles, staging and epilogues, but every product runs as THREE
+// bf16 MFMA passes on split operands, x = hi + lo with hi = bf16(x), lo = bf16(x - hi):  a b ~ ah bh + ah bl + al bh  (fp32 accumulation;
+// the dropped al bl and the split's remainder are ~2^-17 relative - measured on the encoder: max |pre-rounding FSQ value error| 5.8e-4
+// against the reference's fp32 run, every token index equal, tests/probes/split_bf16_probe.py).  The weight operand arrives pre-split
+// (pack time): its fp32-sized image holds, per 16-byte chunk, (hi0..3 | lo0..3) of the chunk's four k values, so it is staged by the
+// very same copies; the token operand is split by the staging threads between the global load and the LDS store (once per element and
+// block).  A lane's chunks kq and kq + 4 of the 32-wide k-tile are the two halves of its 8-element bf16 fragment (hi: dwords x, y of
+// both chunks, lo: z, w) - the same k assignment for both operands, so v_mfma_f32_16x16x32_bf16 pairs equal k.
+__device__ __forceinline__ uint4 split4_bf16(uint4 v) {
+  const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+  const bf16_t h0 = (bf16_t)x0, h1 = (bf16_t)x1, h2 = (bf16_t)x2, h3 = (bf16_t)x3;       // round to nearest even (v_cvt_pk_bf16_f32)
+  const bf16_t l0 = (bf16_t)(x0 - (float)h0), l1 = (bf16_t)(x1 - (float)h1), l2 = (bf16_t)(x2 - (float)h2), l3 = (bf16_t)(x3 - (float)h3);
+  const bf16x4 hv = {h0, h1, h2, h3}, lv = {l0, l1, l2, l3};
+  const uint2 hp = __builtin_bit_cast(uint2, hv), lp = __builtin_bit_cast(uint2, lv);
+  return make_uint4(hp.x, hp.y, lp.x, lp.y);
+}
+
+template <int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
   constexpr int FT = DUAL ? 64 : F_TF;
@@ -1583,6 +1601,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   } while (0)
 #define FLSTORE(buf)                                                                \
   do {                                                                              \
+    if (SPLIT) { sx0 = split4_bf16(sx0); sx1 = split4_bf16(sx1); sx2 = split4_bf16(sx2); sx3 = split4_bf16(sx3); } \
     lds[buf][li0] = sw0; lds[buf][li1] = sw1; lds[buf][li2] = sw2; lds[buf][li3] = sw3;                       \
     lds[buf][F_TF * 8 + li0] = sx0; lds[buf][F_TF * 8 + li1] = sx1; lds[buf][F_TF * 8 + li2] = sx2; lds[buf][F_TF * 8 + li3] = sx3; \
   } while (0)
@@ -1595,6 +1614,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) FGLOAD((kt + 1) * F_BK);
+    if constexpr (SPLIT) {
+      bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+        const uint4 c0 = lds[buf][arow * 8 + (kq ^ (arow & 7))], c1 = lds[buf][arow * 8 + ((kq + 4) ^ (arow & 7))];
+        ah[i] = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+        al[i] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.z, c1.w));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int brow = wt * 64 + j * 16 + l15;
+        const uint4 c0 = lds[buf][F_TF * 8 + brow * 8 + (kq ^ (brow & 7))], c1 = lds[buf][F_TF * 8 + brow * 8 + ((kq + 4) ^ (brow & 7))];
+        bh[j] = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+        bl[j] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.z, c1.w));
+      }
+      // the two cross terms first, the leading term last (small + small + large)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x4 a[4], b[4];
@@ -1615,6 +1664,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
+    }
     }
     if (kt + 1 < nk) FLSTORE(buf ^ 1);
     __syncthreads();
@@ -1707,7 +1757,8 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     }
   } else {
     const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT);
-    hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    if (d.split3) hipLaunchKernelGGL((k_gemm_f32<EPI, true>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    else hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
   }
   TTV_CHECK_LAUNCH("gemm");
   return TTV_OK;
@@ -1776,6 +1827,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end;
   d.eps = a.eps;
   d.debug = g_ttv_debug;
+  d.split3 = (a.split3 && a.dtype == TTV_F32) ? 1 : 0;
+  d.x_mx = d.w_mx = nullptr; d.ld_mx = 0;
   d.norm_gain = a.norm_gain;
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;
   d.x_rows = a.x_rows;

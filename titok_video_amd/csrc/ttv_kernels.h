@@ -26,6 +26,7 @@ int ttvk_histogram(const int* idx, int n, int64_t* counts, int size, hipStream_t
 int ttvk_quant_rows_fp8(const void* in, int in_dtype, int ld_in, const float* gain, float eps, void* out, int ld_out, float* scales, int rows,
                         int d, hipStream_t s);
 
+int ttvk_split3_pack(const float* w, int ldw, void* out, int ldo, int rows, int K, hipStream_t s);
 int64_t ttvk_mx_scale_ld(int d);     // bytes of E8M0 scales per row of width d
 int ttvk_quant_mx_fp8(const void* in, int in_dtype, int ld_in, void* out, int ld_out, void* mx, float* row_scales, int rows, int d, hipStream_t s);
 
@@ -59,6 +60,8 @@ struct GemmArgs {
   int rope_q_end, rope_k_begin, rope_k_end;  // column ranges [0,q_end) and [k_begin,k_end) get rotary
   int dtype;
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
+  int split3;                      // fp32 only: w is the split-bf16 image of the weight (ttv_split3_pack) and the products run as three bf16
+                                   // MFMA passes (k_gemm_f32<.., SPLIT>)
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
   const float* row_scale;          // optional [M]: output row t is multiplied by row_scale[t] before the epilogue (the rstd of a pre-norm
                                    // whose gain is folded into w: any K; bf16 kernels)

@@ -135,7 +135,7 @@ class _Tower(nn.Module):
 
     def _packed(self, dtype: torch.dtype, device) -> "_WeightPack":
         params = self._param_list()
-        key = (dtype, str(device), _versions(params), str(getattr(self, "fp8_linears", False)))
+        key = (dtype, str(device), _versions(params), str(getattr(self, "fp8_linears", False)), bool(getattr(self, "f32_split3", False)))
         if _PACK_CHECK:
             key = key + (float(sum(p.detach().double().sum() for p in params)),)
         if self._pack is None or self._pack_key != key:
@@ -312,10 +312,20 @@ class _WeightPack:
         self.ready = None                              # event recorded on the building stream once every copy / pack kernel is queued
         self.reader_streams = {}                       # stream id -> stream, of every stream a forward read this pack on
 
-        def lin(p):
+        # fp32 towers in split-bf16 mode (tower.f32_split3, inference): the GEMM weights are handed over as split images
+        # (ttv_split3_pack: per four k values hi0..3 | lo0..3 in bf16), same bytes and leading dimension as the fp32 matrix
+        self.f32_split3 = bool(getattr(tower, "f32_split3", False)) and dtype == torch.float32
+
+        def lin(p, gemm_weight=False):
             t = p.detach().to(device=device, dtype=dtype).contiguous()
             keep.append(t)
             self.lin_tensors.append(t)
+            if gemm_weight and self.f32_split3 and t.dim() == 2 and t.shape[1] % 4 == 0:
+                img = torch.empty_like(t)
+                _lib.check(_lib.lib().ttv_split3_pack(t.data_ptr(), t.shape[1], img.data_ptr(), t.shape[1], t.shape[0], t.shape[1], _lib.stream_ptr(device)),
+                           "ttv_split3_pack")
+                keep.append(img)
+                return img.data_ptr()
             return t.data_ptr()
 
         def gain(p):
@@ -449,16 +459,17 @@ class _WeightPack:
                 to_qkv_f8=qkv8, to_qkv_f8_scale=qkv8s, w12_f8=w128, w12_f8_scale=w128s,
                 to_qkv_mx=qkvmx, w12_mx=w12mx, out_proj_f8=wo8, out_proj_f8_scale=wo8s, out_proj_mx=womx,
                 w3_f8=w38, w3_f8_scale=w38s, w3_mx=w3mx,
-                pre_ln=gain(a.pre_ln.weight), to_qkv=lin(a.to_qkv.weight), out_proj=lin(a.out_proj.weight),
-                ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight), w3=lin(f.w3.weight),
+                pre_ln=gain(a.pre_ln.weight), to_qkv=lin(a.to_qkv.weight, True), out_proj=lin(a.out_proj.weight, True),
+                ffd_norm=gain(f.norm.weight), w12=lin(f.w12.weight, True), w3=lin(f.w3.weight, True),
                 attn_post_ln=gain(ml.attn_post_ln[i - 1].weight) if i > 0 else None,
                 ffd_post_ln=gain(ml.ffd_post_ln[i - 1].weight) if i > 0 else None,
                 to_qkv_pn=folded(a.to_qkv.weight, a.pre_ln.weight, q_rows=tower.width), w12_pn=folded(f.w12.weight, f.norm.weight),
                 mlp_pack=pack_ptr, mlp_pack_qkv_rows=pack_rows, qkv_q_prescaled=self.q_prescaled, to_qkv_qs=lin_qs(a.to_qkv.weight))
         self.struct = _lib.TowerWeights(
-            proj_in_w=lin(w_in), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
+            proj_in_w=lin(w_in, tower.kind == _lib.TTV_ENCODER), proj_in_b=lin(tower.proj_in.bias), mask_token=gain(tower.mask_token),
             ln_pre_t=gain(tower.ln_pre_t.weight), ln_pre_p=gain(tower.ln_pre_p.weight), ln_post=gain(tower.ln_post.weight),
-            proj_out_w=lin(w_out), proj_out_b=lin(b_out), layers=self.layers,
+            proj_out_w=lin(w_out, tower.kind == _lib.TTV_DECODER), proj_out_b=lin(b_out), layers=self.layers,
+            f32_split3=1 if self.f32_split3 else 0,
             proj_out_pn=folded(w_out, tower.ln_post.weight) if (tower.kind == _lib.TTV_DECODER and fold) else None)
         self.keep = keep
         self.kind, self.n_layers = tower.kind, n
@@ -613,6 +624,8 @@ class TiTokDecoder(_Tower):
 # autograd: tape-recording forward + hand-written HIP backward (csrc/ttv_train.hip, ttv_bwd.hip)
 # ------------------------------------------------------------------------------------------------------------------
 def _train_ctx(tower: _Tower, pix, counts, device, dtype):
+    if getattr(tower, "f32_split3", False):
+        raise RuntimeError("f32_split3 (split-bf16 arithmetic) is an inference mode: the training towers run plain bf16 / fp32")
     plan = tower._plan(pix, counts, device)
     dims = tower._dims(_lib.dtype_code(dtype))
     batch = plan.batch_for(tower.heads[0], tower.heads[1])

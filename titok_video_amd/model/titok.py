@@ -60,6 +60,19 @@ class TiTok(nn.Module):
         self.encoder_dtype = None
         self.decoder_dtype = None
 
+    def set_index_exact(self, mode):
+        """Inference arithmetic that keeps the reference's fp32 token indices (parameters must be fp32 masters):
+        None     - both towers follow the clips' dtype (the reference's behaviour; default);
+        "fp32"   - encoder on the exact-fp32 MFMA kernels (bit-exact indices), decoder bf16;
+        "split3" - encoder on the split-bf16 three-pass kernels (~2^-17 per product: every index of the benchmark fixture kept, not a
+                   bit-for-bit guarantee), decoder bf16.  About 2.5x the throughput of "fp32"."""
+        if mode not in (None, "fp32", "split3"):
+            raise ValueError("mode must be None, 'fp32' or 'split3'")
+        self.encoder_dtype = None if mode is None else torch.float32
+        self.decoder_dtype = None if mode is None else torch.bfloat16
+        self.encoder.f32_split3 = mode == "split3"
+        return self
+
     # ---- encode ---------------------------------------------------------------------------------------------------------
     def _encode_differentiable(self, clips, counts, grids, split_indices):
         """Training step (train.py:65-83): tape-recording towers with the HIP backward, straight-through FSQ."""
