@@ -1245,7 +1245,7 @@ template <bool GATE>
 __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
                                                         const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
                                                         int rep, float c_exp /* scale * log2(e) */) {
-  __shared__ __attribute__((aligned(16))) uint4 tiles[4][KB * 8];      // K hi, K lo, V hi, V lo: 64 keys x 128 bytes each
+  __shared__ __attribute__((aligned(16))) uint4 tiles[2][4][KB * 8];   // two stages of (K hi, K lo, V hi, V lo), 64 keys x 128 bytes each
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -1291,22 +1291,21 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
   // bf16 tile row = 128 bytes = 8 chunks of 16 bytes; float chunk sch is the 8-byte half sch & 1 of chunk sch >> 1, stored at the
   // swizzled chunk position k_attn_bf16's fragment reads expect: K: c ^ ((row >> 1) & 7), V: c ^ (((row >> 1) & 1) << 2).
   // Rows skey + 16 i: (row >> 1) & 7 and (row >> 1) & 1 do not depend on i.
-  char* const tk_h = reinterpret_cast<char*>(&tiles[0][0]);
-  char* const tk_l = reinterpret_cast<char*>(&tiles[1][0]);
-  char* const tv_h = reinterpret_cast<char*>(&tiles[2][0]);
-  char* const tv_l = reinterpret_cast<char*>(&tiles[3][0]);
+  char* const tile0 = reinterpret_cast<char*>(&tiles[0][0][0]);
+  constexpr int STAGE = 4 * KB * 128, PLANE = KB * 128;
   const int kst = skey * 128 + (((sch >> 1) ^ ((skey >> 1) & 7)) << 4) + (sch & 1) * 8;
   const int vst = skey * 128 + (((sch >> 1) ^ (((skey >> 1) & 1) << 2)) << 4) + (sch & 1) * 8;
-#define S3_LSTORE()                                                                        \
+#define S3_LSTORE(stage_)                                                                  \
   do {                                                                                     \
+    char* const sb__ = tile0 + (stage_) * STAGE;                                           \
     _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                  \
       uint2 hi__, lo__;                                                                    \
       split4_f32(sk[i__], hi__, lo__);                                                     \
-      *reinterpret_cast<uint2*>(tk_h + kst + i__ * 2048) = hi__;                           \
-      *reinterpret_cast<uint2*>(tk_l + kst + i__ * 2048) = lo__;                           \
+      *reinterpret_cast<uint2*>(sb__ + kst + i__ * 2048) = hi__;                           \
+      *reinterpret_cast<uint2*>(sb__ + PLANE + kst + i__ * 2048) = lo__;                   \
       split4_f32(sv[i__], hi__, lo__);                                                     \
-      *reinterpret_cast<uint2*>(tv_h + vst + i__ * 2048) = hi__;                           \
-      *reinterpret_cast<uint2*>(tv_l + vst + i__ * 2048) = lo__;                           \
+      *reinterpret_cast<uint2*>(sb__ + 2 * PLANE + vst + i__ * 2048) = hi__;               \
+      *reinterpret_cast<uint2*>(sb__ + 3 * PLANE + vst + i__ * 2048) = lo__;               \
     }                                                                                      \
   } while (0)
 
@@ -1329,13 +1328,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
+  // two LDS stages, one barrier per tile: while a wave computes on stage kt & 1 it has already written tile kt + 1 into the other stage
+  // (from the registers loaded one tile earlier) and has tile kt + 2's global loads in flight
   S3_GLOAD(0);
+  S3_LSTORE(0);
+  if (nkt > 1) S3_GLOAD(1);
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();            // every wave is done with the previous tile
-    S3_LSTORE();
-    __syncthreads();
-    if (kt + 1 < nkt) S3_GLOAD(kt + 1);   // in flight behind this tile's MFMAs
+    __syncthreads();            // stage kt & 1 is complete; every wave is done computing on the other stage
+    if (kt + 1 < nkt) {
+      S3_LSTORE((kt + 1) & 1);
+      if (kt + 2 < nkt) S3_GLOAD(kt + 2);
+    }
     if (!wave_live) continue;
+    const char* const tk_h = tile0 + (kt & 1) * STAGE;
+    const char* const tk_l = tk_h + PLANE;
+    const char* const tv_h = tk_h + 2 * PLANE;
+    const char* const tv_l = tk_h + 3 * PLANE;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {          // two 32-key sub-tiles
       if (kt * KB + t * 32 >= S) break;    // wave-uniform

@@ -56,6 +56,16 @@ struct PatchDst {
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// split-bf16 towers: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7 - two orders below the 2^-17 of the three-pass products;
+// the exact-fp32 towers keep libm's erff): one v_rcp, one v_exp and a degree-5 Horner chain instead of ~50 branchy instructions
+__device__ __forceinline__ float gelu_erf_as(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  return 0.5f * v * (1.0f + __builtin_copysignf(erf_abs, v));
+}
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16 resolution) for the bf16 GEGLU epilogue:
 // one v_rcp, one v_exp and a degree-5 Horner chain instead of libm's branchy erff.
@@ -166,6 +176,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
         if (sizeof(T) == 2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i][j][e] = geglu_fast(acc2[i][j][e], acc[i][j][e]);
+        } else if (p.split3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = gelu_erf_as(acc2[i][j][e]) * acc[i][j][e];
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i][j][e] = gelu_erf(acc2[i][j][e]) * acc[i][j][e];
@@ -1543,67 +1556,59 @@ __device__ __forceinline__ uint4 split4_bf16(uint4 v) {
   return make_uint4(hp.x, hp.y, lp.x, lp.y);
 }
 
-template <int EPI, bool SPLIT = false>
+template <int EPI, bool SPLIT = false, int NJ = 4>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
   constexpr int FT = DUAL ? 64 : F_TF;
-  __shared__ uint4 lds[2][(F_TF + F_TT) * 8];   // [buffer][w rows 0..127 | x rows 0..127][row*8 + swizzled chunk], 2 x 32 KiB
+  constexpr int TTK = 32 * NJ;                  // tokens per block: 128, or 160 where that saves a round of resident blocks (launch())
+  __shared__ uint4 lds[2][(F_TF + TTK) * 8];    // [buffer][w rows 0..127 | x rows 0..TTK-1][row*8 + swizzled chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wf = wave & 1, wt = wave >> 1;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int fbase = (tile % n_ftiles) * FT;
-  const int tbase = (tile / n_ftiles) * F_TT;
+  const int tbase = (tile / n_ftiles) * TTK;
   const float* W = (const float*)p.w;
   const float* X = (const float*)p.x;
 
-  // staging: 1024 chunks per operand and k-step, 4 per thread: row = (tid >> 3) + 32 i, chunk kc = tid & 7
+  // staging: 8 chunks per row and k-step; thread -> row (tid >> 3) + 32 i, chunk kc = tid & 7: 4 weight rows and NJ token rows per thread
   const int srow = tid >> 3, skc = tid & 7;
-  const float* wp0; const float* wp1; const float* wp2; const float* wp3;
-  const float* xp0; const float* xp1; const float* xp2; const float* xp3;
-  {
-    auto wrow = [&](int row) {
-      int wr;
-      if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
-      else wr = fbase + row;
-      wr = wr < p.w_rows ? wr : p.w_rows - 1;
-      return W + (size_t)wr * p.ldw + skc * 4;
-    };
-    auto xrow = [&](int row) {
-      int xr = tbase + row;
-      xr = xr < p.M ? xr : p.M - 1;
-      return X + (size_t)xr * p.ldx + skc * 4;
-    };
-    wp0 = wrow(srow); wp1 = wrow(srow + 32); wp2 = wrow(srow + 64); wp3 = wrow(srow + 96);
-    xp0 = xrow(srow); xp1 = xrow(srow + 32); xp2 = xrow(srow + 64); xp3 = xrow(srow + 96);
+  const float* wp[4];
+  const float* xp[NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = srow + 32 * i;
+    int wr;
+    if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
+    else wr = fbase + row;
+    wr = wr < p.w_rows ? wr : p.w_rows - 1;
+    wp[i] = W + (size_t)wr * p.ldw + skc * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    int xr = tbase + srow + 32 * i;
+    xr = xr < p.M ? xr : p.M - 1;
+    xp[i] = X + (size_t)xr * p.ldx + skc * 4;
   }
   const int li0 = srow * 8 + (skc ^ (srow & 7));            // (srow + 32 i) & 7 == srow & 7
-  const int li1 = li0 + 32 * 8, li2 = li0 + 64 * 8, li3 = li0 + 96 * 8;
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 sw0, sw1, sw2, sw3, sx0, sx1, sx2, sx3;
+  uint4 sw[4], sx[NJ];
   const uint4 zero4 = {0u, 0u, 0u, 0u};
 #define FGLOAD(k0)                                                                  \
   do {                                                                              \
     const bool ok__ = ((k0) + skc * 4) < p.K;                                       \
-    sw0 = ok__ ? *reinterpret_cast<const uint4*>(wp0 + (k0)) : zero4;               \
-    sw1 = ok__ ? *reinterpret_cast<const uint4*>(wp1 + (k0)) : zero4;               \
-    sw2 = ok__ ? *reinterpret_cast<const uint4*>(wp2 + (k0)) : zero4;               \
-    sw3 = ok__ ? *reinterpret_cast<const uint4*>(wp3 + (k0)) : zero4;               \
-    sx0 = ok__ ? *reinterpret_cast<const uint4*>(xp0 + (k0)) : zero4;               \
-    sx1 = ok__ ? *reinterpret_cast<const uint4*>(xp1 + (k0)) : zero4;               \
-    sx2 = ok__ ? *reinterpret_cast<const uint4*>(xp2 + (k0)) : zero4;               \
-    sx3 = ok__ ? *reinterpret_cast<const uint4*>(xp3 + (k0)) : zero4;               \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) sw[i__] = ok__ ? *reinterpret_cast<const uint4*>(wp[i__] + (k0)) : zero4;  \
+    _Pragma("unroll") for (int i__ = 0; i__ < NJ; ++i__) sx[i__] = ok__ ? *reinterpret_cast<const uint4*>(xp[i__] + (k0)) : zero4; \
   } while (0)
 #define FLSTORE(buf)                                                                \
   do {                                                                              \
-    if (SPLIT) { sx0 = split4_bf16(sx0); sx1 = split4_bf16(sx1); sx2 = split4_bf16(sx2); sx3 = split4_bf16(sx3); } \
-    lds[buf][li0] = sw0; lds[buf][li1] = sw1; lds[buf][li2] = sw2; lds[buf][li3] = sw3;                       \
-    lds[buf][F_TF * 8 + li0] = sx0; lds[buf][F_TF * 8 + li1] = sx1; lds[buf][F_TF * 8 + li2] = sx2; lds[buf][F_TF * 8 + li3] = sx3; \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) lds[buf][li0 + i__ * 32 * 8] = sw[i__];                                   \
+    _Pragma("unroll") for (int i__ = 0; i__ < NJ; ++i__) lds[buf][F_TF * 8 + li0 + i__ * 32 * 8] = SPLIT ? split4_bf16(sx[i__]) : sx[i__]; \
   } while (0)
 
   const int l15 = lane & 15, kq = lane >> 4;
@@ -1615,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
     const int buf = kt & 1;
     if (kt + 1 < nk) FGLOAD((kt + 1) * F_BK);
     if constexpr (SPLIT) {
-      bf16x8 ah[4], al[4], bh[4], bl[4];
+      bf16x8 ah[4], al[4], bh[NJ], bl[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
@@ -1624,8 +1629,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
         al[i] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.z, c1.w));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int brow = wt * 64 + j * 16 + l15;
+      for (int j = 0; j < NJ; ++j) {
+        const int brow = wt * (16 * NJ) + j * 16 + l15;
         const uint4 c0 = lds[buf][F_TF * 8 + brow * 8 + (kq ^ (brow & 7))], c1 = lds[buf][F_TF * 8 + brow * 8 + ((kq + 4) ^ (brow & 7))];
         bh[j] = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
         bl[j] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.z, c1.w));
@@ -1634,37 +1639,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x4 a[4], b[4];
-      const int kc = kb * 4 + kq;
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x4 a[4], b[NJ];
+        const int kc = kb * 4 + kq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
-        a[i] = __builtin_bit_cast(f32x4, lds[buf][arow * 8 + (kc ^ (arow & 7))]);
+        for (int i = 0; i < 4; ++i) {
+          const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+          a[i] = __builtin_bit_cast(f32x4, lds[buf][arow * 8 + (kc ^ (arow & 7))]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int brow = wt * (16 * NJ) + j * 16 + l15;
+          b[j] = __builtin_bit_cast(f32x4, lds[buf][F_TF * 8 + brow * 8 + (kc ^ (brow & 7))]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int brow = wt * 64 + j * 16 + l15;
-        b[j] = __builtin_bit_cast(f32x4, lds[buf][F_TF * 8 + brow * 8 + (kc ^ (brow & 7))]);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
-    }
     }
     if (kt + 1 < nk) FLSTORE(buf ^ 1);
     __syncthreads();
@@ -1672,24 +1677,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
 #undef FGLOAD
 #undef FLSTORE
 
-  int tok[4];
+  int tok[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tok[j] = tbase + wt * 64 + j * 16 + l15;
+  for (int j = 0; j < NJ; ++j) tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
   if (DUAL) {
     int feat[2];
-    f32x4 ax[2][4], ag[2][4];
+    f32x4 ax[2][NJ], ag[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
+      for (int j = 0; j < NJ; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
     }
-    epilogue_tile<EPI, float, 2, 4>(p, tok, feat, ax, ag, kq);
+    epilogue_tile<EPI, float, 2, NJ>(p, tok, feat, ax, ag, kq);
   } else {
     int feat[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
-    epilogue_tile<EPI, float, 4, 4>(p, tok, feat, acc, acc, kq);
+    epilogue_tile<EPI, float, 4, NJ>(p, tok, feat, acc, acc, kq);
   }
 }
 
@@ -1756,9 +1761,18 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
       else hipLaunchKernelGGL((k_gemm_bf16<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
     }
   } else {
-    const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT);
-    if (d.split3) hipLaunchKernelGGL((k_gemm_f32<EPI, true>), dim3(nf * nt), dim3(256), 0, s, d, nf);
-    else hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    // 128- or 160-token tiles by the same rounds-of-512-resident-blocks rule as the bf16 kernel: N = 256 at the benchmark batch is 576
+    // tiles of 128 tokens - two rounds, the second an eighth full - and 462 tiles of 160 in one
+    const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT), nt160 = ttv_cdiv(d.M, 160);
+    const long c128 = (long)ttv_cdiv(nf * nt, 512) * 128, c160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
+    const bool t160 = ((c160 < c128) && !(d.debug & 256)) || (d.debug & 128);
+    if (d.split3) {
+      if (t160) hipLaunchKernelGGL((k_gemm_f32<EPI, true, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+      else hipLaunchKernelGGL((k_gemm_f32<EPI, true, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    } else {
+      if (t160) hipLaunchKernelGGL((k_gemm_f32<EPI, false, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+      else hipLaunchKernelGGL((k_gemm_f32<EPI, false, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    }
   }
   TTV_CHECK_LAUNCH("gemm");
   return TTV_OK;
