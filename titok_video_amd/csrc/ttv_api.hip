@@ -135,6 +135,9 @@ static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, co
 static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const TowerWs& ws, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
   const int split3 = (dt == TTV_F32 && w->f32_split3) ? 1 : 0;       // fp32 towers on the three-pass bf16 kernels (ttv_tower_weights.f32_split3)
+  // pre-norm gains folded into the weight (to_qkv_pn / w12_pn) with the row statistic applied to the GEMM's output rows: the wide bf16
+  // towers, and the split-bf16 towers of any width (their weights are repacked anyway; the exact-fp32 towers keep the reference's order)
+  const bool gen_ok = (dt == TTV_BF16 && dm != 256) || split3;
   const int nq = 2 * dm + 2 * g;
   bool qkv_ready = false;   // the previous layer's tail kernel already produced this layer's rotated qkv
   bool rstd_valid = false;  // ws.rstd holds rsqrt(mean(x^2) + eps) of the current ws.x (written by the kernel that produced x)
@@ -165,7 +168,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       // other widths: the gain is folded into the weight as well (to_qkv_pn), the row statistic comes from the kernel that
       // produced x (the KEEL post-norm below writes it) or from one light pass, and multiplies the GEMM's output rows - no
       // stand-alone RMSNorm launch, no normalised copy of x
-      const bool fold_gen = dt == TTV_BF16 && dm != 256 && lw.to_qkv_pn;
+      const bool fold_gen = gen_ok && lw.to_qkv_pn;
       if (fold_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
       if (!fold_qkv && !fold_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
       GemmArgs a = {};
@@ -223,7 +226,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       // in the compute dtype, in place on x (a token row element is read as residual and written by the same lane) - the reference's
       // autocast rounds that sum to bf16 as well (transformer.py:141: bf16 * alpha + bf16) -: half the bytes of the fp32 buffer on
       // both kernels.  fp32 towers, and TTV_KEEL_F32SUM=1 (A/B), keep the fp32 buffer.
-      const bool want = dt == TTV_BF16 && dm != 256 && lw.w12_pn && !f8_w12;
+      const bool want = gen_ok && lw.w12_pn && !f8_w12;
       if (dt == TTV_BF16 && !keel_f32sum) {
         o.alpha = d->alpha; o.y = ws.x; o.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
@@ -237,7 +240,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     }
     // ---- GEGLU sub-layer (transformer.py:47-56) ----
     const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
-    const bool fold_ffd_gen = dt == TTV_BF16 && dm != 256 && lw.w12_pn && !f8_w12;
+    const bool fold_ffd_gen = gen_ok && lw.w12_pn && !f8_w12;
     if (f8_w12) {
       TTV_TRY(ttvk_quant_rows_fp8(ws.x, dt, dm, lw.ffd_norm, d->eps, ws.xn, dm, f8_scales, L, dm, s));
       GemmArgs f = {};
@@ -265,7 +268,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
-      const bool want = dt == TTV_BF16 && dm != 256 && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn && !(w->layers[i + 1].to_qkv_f8 && w->layers[i + 1].to_qkv_f8_scale);
+      const bool want = gen_ok && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn && !(w->layers[i + 1].to_qkv_f8 && w->layers[i + 1].to_qkv_f8_scale);
       if (dt == TTV_BF16 && !keel_f32sum) {      // see the attention sub-layer above
         f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));

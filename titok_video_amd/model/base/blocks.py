@@ -404,6 +404,13 @@ class _WeightPack:
 
         def folded(w, g, q_rows=0):
             """w * gain[None, :] in fp32, then the compute dtype: lets the GEMM absorb the pre-norm."""
+            if self.f32_split3:       # split-bf16 towers: the folded matrix as a split image (the GEMM scales its rows by the pre-norm's rstd)
+                t = (w.detach().to(device=device, dtype=torch.float32) * g.detach().to(device=device, dtype=torch.float32)[None, :]).contiguous()
+                img = torch.empty_like(t)
+                _lib.check(_lib.lib().ttv_split3_pack(t.data_ptr(), t.shape[1], img.data_ptr(), t.shape[1], t.shape[0], t.shape[1], _lib.stream_ptr(device)),
+                           "ttv_split3_pack")
+                keep.extend([t, img])
+                return img.data_ptr()
             if not (fold or fold_gen):
                 return None
             t = folded_tensor(w, g, q_rows)
