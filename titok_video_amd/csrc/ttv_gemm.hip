@@ -1848,7 +1848,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.x_rows = a.x_rows;
   d.x_scale = nullptr; d.w_scale = nullptr;
   d.row_scale = a.row_scale;
-  TTV_CHECK_ARG(!a.row_scale || (a.dtype == TTV_BF16 && (epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU)), "gemm: row_scale is a bf16 STORE / QKV_ROPE / GEGLU option");
+  TTV_CHECK_ARG(!a.row_scale || ((a.dtype == TTV_BF16 || a.split3) && (epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU)),
+                "gemm: row_scale is a STORE / QKV_ROPE / GEGLU option of the bf16 and the split-bf16 kernels");
   TTV_CHECK_ARG(!a.x_rows || (a.dtype == TTV_BF16 && a.K == 256 && a.N % 8 == 0 && epi != EPI_RESID_NORM), "gemm: x_rows needs the bf16 K=256 kernel");
   if (epi == EPI_STORE_PATCH || a.gather) {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
