@@ -23,6 +23,12 @@ from ..base.utils import init_weights
 from ...train import l1_reconstruction_loss
 
 
+import os
+
+_F32_HEAD = os.environ.get("TTV_DISC_F32_HEAD", "0") == "1"
+_TWO_CALLS = os.environ.get("TTV_DISC_TWO_CALLS", "0") == "1"
+
+
 class ReconstructionLoss(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -49,7 +55,10 @@ class ReconstructionLoss(nn.Module):
     def disc_wrapper(self, x: Sequence[torch.Tensor]) -> torch.Tensor:
         """One logit per clip: the mean of the clip's 4 register-token outputs (loss_module.py:96-101)."""
         n = len(x)
-        per_token = self.disc_model(list(x), [self.disc_tokens] * n)          # [4 n, 1]
+        if _F32_HEAD:    # the tower's fp32 token outputs, averaged in fp32: no bf16 rounding of the logits themselves
+            per_token = self.disc_model.forward_z(list(x), [self.disc_tokens] * n)  # fp32 [4 n, 1]
+        else:            # the reference's dtype flow (encoder output cast to the clips' dtype, blocks.py:103)
+            per_token = self.disc_model(list(x), [self.disc_tokens] * n)          # [4 n, 1]
         return per_token.view(n, -1).mean(dim=-1)
 
     def _set_disc_trainable(self, flag: bool) -> None:
@@ -96,8 +105,14 @@ class ReconstructionLoss(nn.Module):
         if use_penalty:
             if noise is None:
                 noise = [torch.randn_like(t) * self.gp_noise for t in real]
-            packed = packed + [t + e for t, e in zip(real, noise)] + [f + e for f, e in zip(fake, noise)]
-        scores = self.disc_wrapper(packed).view(-1, len(real))                # rows: real, fake, (real + noise, fake + noise)
+            noisy = [t + e for t, e in zip(real, noise)] + [f + e for f, e in zip(fake, noise)]
+        if use_penalty and _TWO_CALLS:
+            # two packed calls with IDENTICAL plans: clip j and its noisy copy sit at the same packed rows of their call
+            scores = torch.cat([self.disc_wrapper(packed), self.disc_wrapper(noisy)]).view(-1, len(real))
+        else:
+            if use_penalty:
+                packed = packed + noisy
+            scores = self.disc_wrapper(packed).view(-1, len(real))            # rows: real, fake, (real + noise, fake + noise)
         score_real, score_fake = scores[0], scores[1]
         margin = score_real - score_fake
         terms = {"d_loss": F.softplus(-margin), "logits_relative": margin}
