@@ -18,6 +18,25 @@ if [ $PART = tiny2 ]; then
   step knock-outs of the 64-row kernel; for n in dma lds max exp all; do echo "== knock-out $n" >> $O/attn64_knockouts.txt; TTV_LIB_PATH=$R/titok_video_amd/csrc/build/libtitok_hip_ko64_$n.so FP32=0 python3 $R/tools/attn_bench.py 1.5 2>&1 | grep "w64" >> $O/attn64_knockouts.txt; done
   step loss probe; TAG=default python3 $R/tools/loss_probe.py > $O/loss_probe.txt 2>&1; TAG=thr0 TTV_ATTN_THR=0 python3 $R/tools/loss_probe.py >> $O/loss_probe.txt 2>&1
 fi
+if [ $PART = r04 ]; then       # round 4 evidence set: the driver's command, both modes under rocprof, traffic counters, base / base5, exact index
+  step bench default; timeout -k 10 500 python3 $R/bench.py > $O/tiny_bench.json 2> $O/tiny_bench.err
+  step bench in-flight 1; timeout -k 10 300 python3 $R/bench.py --in-flight 1 --no-cpu-baseline --no-side-legs > $O/tiny_bench_inflight1.json 2>> $O/tiny_bench.err
+  step rocprof two chains; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -o p -- python3 $R/bench.py --no-cpu-baseline --no-fp32-leg --no-side-legs > $O/tiny_bench_under_rocprof.json 2> $O/prof_if2.log
+  step rocprof one chain; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -o p -- python3 $R/bench.py --in-flight 1 --no-cpu-baseline --no-fp32-leg --no-side-legs > $O/tiny_bench_inflight1_under_rocprof.json 2> $O/prof_if1.log
+  step pmc fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python3 $R/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-leg --no-side-legs > /dev/null 2> $O/pmc_f.log
+  step pmc write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python3 $R/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-leg --no-side-legs > /dev/null 2> $O/pmc_w.log
+  step exact index; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s3 -o p -- python3 $R/tools/exact_index_bench.py > $O/exact_index_split3.txt 2> $O/prof_s3.log
+  MODE=fp32 timeout -k 10 300 python3 $R/tools/exact_index_bench.py > $O/exact_index_fp32.txt 2>&1
+  find $O -name "*kernel_trace.csv" -delete
+fi
+if [ $PART = r04base ]; then
+  step base; timeout -k 10 300 python3 $R/bench.py --config base > $O/base_bench.json 2> $O/base_bench.err
+  step base5; timeout -k 10 300 python3 $R/bench.py --config base5 > $O/base5_bench.json 2>> $O/base_bench.err
+  step base5 decoder only; timeout -k 10 200 python3 $R/bench.py --config base5 --fp8 mx-decoder --no-cpu-baseline --no-fp32-leg > $O/base5_decoder_only_bench.json 2>> $O/base_bench.err
+  step base rocprof; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_base -o p -- python3 $R/bench.py --config base --in-flight 1 --no-cpu-baseline --no-fp32-leg > $O/base_bench_inflight1_under_rocprof.json 2> $O/prof_base.log
+  step base5 rocprof; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_base5 -o p -- python3 $R/bench.py --config base5 --in-flight 1 --no-cpu-baseline --no-fp32-leg > $O/base5_bench_inflight1_under_rocprof.json 2> $O/prof_base5.log
+  find $O -name "*kernel_trace.csv" -delete
+fi
 if [ $PART = tiny ]; then
   step bench default; python3 $R/bench.py > $O/tiny_bench.json 2> $O/tiny_bench.err
   step bench in-flight 1; python3 $R/bench.py --in-flight 1 --no-cpu-baseline > $O/tiny_bench_inflight1.json 2>> $O/tiny_bench.err
