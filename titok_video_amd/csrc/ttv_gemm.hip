@@ -1572,8 +1572,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
 
   // staging: 8 chunks per row and k-step; thread -> row (tid >> 3) + 32 i, chunk kc = tid & 7: 4 weight rows and NJ token rows per thread
   const int srow = tid >> 3, skc = tid & 7;
-  const float* wp[4];
-  const float* xp[NJ];
+  // element offsets, not pointers: arrays of 64-bit pointers end up in scratch here (and every staging load then waits for a scratch
+  // reload); 32-bit offsets stay in registers.  M * ldx and w_rows * ldw < 2^31 elements is checked by the launcher.
+  uint32_t wo[4], xo[NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = srow + 32 * i;
@@ -1581,13 +1582,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
     if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
     else wr = fbase + row;
     wr = wr < p.w_rows ? wr : p.w_rows - 1;
-    wp[i] = W + (size_t)wr * p.ldw + skc * 4;
+    wo[i] = (uint32_t)wr * (uint32_t)p.ldw + (uint32_t)(skc * 4);
   }
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
     int xr = tbase + srow + 32 * i;
     xr = xr < p.M ? xr : p.M - 1;
-    xp[i] = X + (size_t)xr * p.ldx + skc * 4;
+    xo[i] = (uint32_t)xr * (uint32_t)p.ldx + (uint32_t)(skc * 4);
   }
   const int li0 = srow * 8 + (skc ^ (srow & 7));            // (srow + 32 i) & 7 == srow & 7
 
@@ -1597,18 +1598,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 sw[4], sx[NJ];
+  // named staging registers (sx4 only with the 160-token tile): written as arrays the compiler keeps some of them in scratch
+  uint4 sw0, sw1, sw2, sw3, sx0, sx1, sx2, sx3, sx4;
   const uint4 zero4 = {0u, 0u, 0u, 0u};
+  const uint32_t wo0 = wo[0], wo1 = wo[1], wo2 = wo[2], wo3 = wo[3];
+  const uint32_t xo0 = xo[0], xo1 = xo[1], xo2 = xo[2], xo3 = xo[3], xo4 = xo[NJ - 1];
 #define FGLOAD(k0)                                                                  \
   do {                                                                              \
     const bool ok__ = ((k0) + skc * 4) < p.K;                                       \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) sw[i__] = ok__ ? *reinterpret_cast<const uint4*>(wp[i__] + (k0)) : zero4;  \
-    _Pragma("unroll") for (int i__ = 0; i__ < NJ; ++i__) sx[i__] = ok__ ? *reinterpret_cast<const uint4*>(xp[i__] + (k0)) : zero4; \
+    sw0 = ok__ ? *reinterpret_cast<const uint4*>(W + wo0 + (k0)) : zero4;           \
+    sw1 = ok__ ? *reinterpret_cast<const uint4*>(W + wo1 + (k0)) : zero4;           \
+    sw2 = ok__ ? *reinterpret_cast<const uint4*>(W + wo2 + (k0)) : zero4;           \
+    sw3 = ok__ ? *reinterpret_cast<const uint4*>(W + wo3 + (k0)) : zero4;           \
+    sx0 = ok__ ? *reinterpret_cast<const uint4*>(X + xo0 + (k0)) : zero4;           \
+    sx1 = ok__ ? *reinterpret_cast<const uint4*>(X + xo1 + (k0)) : zero4;           \
+    sx2 = ok__ ? *reinterpret_cast<const uint4*>(X + xo2 + (k0)) : zero4;           \
+    sx3 = ok__ ? *reinterpret_cast<const uint4*>(X + xo3 + (k0)) : zero4;           \
+    if (NJ == 5) sx4 = ok__ ? *reinterpret_cast<const uint4*>(X + xo4 + (k0)) : zero4; \
   } while (0)
+#define FSPLIT(v_) (SPLIT ? split4_bf16(v_) : (v_))
 #define FLSTORE(buf)                                                                \
   do {                                                                              \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) lds[buf][li0 + i__ * 32 * 8] = sw[i__];                                   \
-    _Pragma("unroll") for (int i__ = 0; i__ < NJ; ++i__) lds[buf][F_TF * 8 + li0 + i__ * 32 * 8] = SPLIT ? split4_bf16(sx[i__]) : sx[i__]; \
+    lds[buf][li0] = sw0; lds[buf][li0 + 32 * 8] = sw1; lds[buf][li0 + 64 * 8] = sw2; lds[buf][li0 + 96 * 8] = sw3;            \
+    lds[buf][F_TF * 8 + li0] = FSPLIT(sx0); lds[buf][F_TF * 8 + li0 + 32 * 8] = FSPLIT(sx1);                                  \
+    lds[buf][F_TF * 8 + li0 + 64 * 8] = FSPLIT(sx2); lds[buf][F_TF * 8 + li0 + 96 * 8] = FSPLIT(sx3);                          \
+    if (NJ == 5) lds[buf][F_TF * 8 + li0 + 128 * 8] = FSPLIT(sx4);                                                            \
   } while (0)
 
   const int l15 = lane & 15, kq = lane >> 4;
@@ -1676,6 +1690,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   }
 #undef FGLOAD
 #undef FLSTORE
+#undef FSPLIT
 
   int tok[NJ];
 #pragma unroll
@@ -1763,6 +1778,10 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
   } else {
     // 128- or 160-token tiles by the same rounds-of-512-resident-blocks rule as the bf16 kernel: N = 256 at the benchmark batch is 576
     // tiles of 128 tokens - two rounds, the second an eighth full - and 462 tiles of 160 in one
+    if ((uint64_t)d.M * (uint64_t)d.ldx >= (1ull << 31) || (uint64_t)d.w_rows * (uint64_t)d.ldw >= (1ull << 31)) {
+      ttv_set_error("gemm (fp32): operand too large for 32-bit element offsets");
+      return TTV_ERR_UNSUPPORTED;
+    }
     const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT), nt160 = ttv_cdiv(d.M, 160);
     const long c128 = (long)ttv_cdiv(nf * nt, 512) * 128, c160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
     const bool t160 = ((c160 < c128) && !(d.debug & 256)) || (d.debug & 128);
