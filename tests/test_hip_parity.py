@@ -624,3 +624,48 @@ def test_base_cfg4_bf16_vs_reference():
     e_mine, e_ref16 = float((mine - ref).norm() / ref.norm()), float((ref16 - ref).norm() / ref.norm())
     print(f"   decoder rel. error vs fp32 reference: HIP {e_mine:.5f} | reference-in-bf16 {e_ref16:.5f}")
     assert e_mine <= 1.15 * e_ref16 + 1e-3
+
+
+def test_base_cfg5_mx_fp8_towers_with_the_16384x64_codebook_on_one_full_size_clip():
+    """BASELINE config #5 as ONE thing (missing #1): base towers, one 32x256x256 clip, K = 1024 latent tokens, the L2
+    quantiser with a 16384 x 64 codebook wired into TiTok, all four linears of every layer in block-scaled (MX) e4m3 - against the CPU
+    oracle towers (fp32) + the cdist oracle.  Not reference-pinned by construction (the reference has neither an L2 quantiser nor fp8):
+    the oracle restates the model, the MX arithmetic is pinned kernel by kernel in tests/test_hip_fp8.py.
+    Stated tolerance (e4m3 keeps 3 mantissa bits, 96 quantised linears in a row): pre-quantisation tokens z within 0.30 relative
+    (Frobenius) of the fp32 oracle - the bf16 towers: ~0.04, printed -, decoder reconstruction of the ORACLE's codes within 0.15 relative;
+    token indices are not preserved by fp8 towers (agreement with the oracle and with the bf16 towers is printed, and must be far above
+    chance - 1 / 16384 - because the codebook is coarse against the tokens' error)."""
+    from types import SimpleNamespace
+    from oracle import vq_oracle as V
+    n_entries, width, count, shape = 16384, 64, 1024, (32, 256, 256)
+    cfg = SimpleNamespace(tokenizer=SimpleNamespace(model=SimpleNamespace(
+        patch_size=[4, 8, 8], fsq_levels=None, quantizer="l2", codebook_size=n_entries, token_size=width, encoder_size="base", decoder_size="base")))
+    sd = seeded_titok_state(0, "base", "base", token_size=width, gain=3.0)
+    cb = torch.randn(n_entries, width, generator=torch.Generator().manual_seed(5)) * 1.5
+    clip_cpu = synthetic_clips([shape], seed=4044)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        z_ref = O.encoder_forward(clip_cpu, [count], sd, "base", prefix="encoder.")
+        idx_ref, _, _gap = V.l2_argmin(z_ref, cb)
+        rec_ref = O.decoder_forward(cb[idx_ref.long()], [count], [shape], sd, "base", prefix="decoder.")[0]
+    res = {}
+    for mode in (False, "mx"):
+        m = TiTok(cfg)
+        m.load_state_dict({**sd, "quantize.codebook": cb}, strict=True)
+        m = m.to(DEV, torch.bfloat16).eval()
+        m.encoder.fp8_linears = m.decoder.fp8_linears = mode
+        clips = [c.to(DEV, torch.bfloat16) for c in clip_cpu]
+        with torch.no_grad():
+            z = m.encoder.run(clips, [count], None, None, want_z=True)["z"].float().cpu()
+            recon, info = m(clips, [count])                                           # the whole forward, as bench.py --config base5 times it
+            rec_o = m.decode(cb[idx_ref.long()].to(DEV, torch.bfloat16), [count], [shape])[0].float().cpu()
+        assert recon[0].shape == (3,) + shape and info["indices"].shape == (count,)
+        res[mode] = dict(z=float((z - z_ref).norm() / z_ref.norm()), idx=info["indices"].cpu(),
+                         dec=float((rec_o - rec_ref).norm() / rec_ref.norm()))
+    agree = lambda a, b: float((a == b).float().mean())
+    print(f"base cfg5, one 32x256x256 clip: z rel. error bf16 {res[False]['z']:.4f} | mx-fp8 {res['mx']['z']:.4f}; decoder rel. error on the oracle's codes "
+          f"bf16 {res[False]['dec']:.4f} | mx-fp8 {res['mx']['dec']:.4f}; indices equal to the fp32 oracle's: bf16 {agree(res[False]['idx'], idx_ref):.3f} | "
+          f"mx-fp8 {agree(res['mx']['idx'], idx_ref):.3f}; mx-fp8 vs bf16 towers {agree(res['mx']['idx'], res[False]['idx']):.3f}")
+    assert res["mx"]["z"] < 0.30 and res["mx"]["dec"] < 0.15
+    assert res[False]["z"] < 0.08
+    assert agree(res["mx"]["idx"], idx_ref) > 0.05
