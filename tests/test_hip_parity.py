@@ -631,10 +631,10 @@ def test_base_cfg5_mx_fp8_towers_with_the_16384x64_codebook_on_one_full_size_cli
     quantiser with a 16384 x 64 codebook wired into TiTok, all four linears of every layer in block-scaled (MX) e4m3 - against the CPU
     oracle towers (fp32) + the cdist oracle.  Not reference-pinned by construction (the reference has neither an L2 quantiser nor fp8):
     the oracle restates the model, the MX arithmetic is pinned kernel by kernel in tests/test_hip_fp8.py.
-    Stated tolerance (e4m3 keeps 3 mantissa bits, 96 quantised linears in a row): pre-quantisation tokens z within 0.30 relative
-    (Frobenius) of the fp32 oracle - the bf16 towers: ~0.04, printed -, decoder reconstruction of the ORACLE's codes within 0.15 relative;
-    token indices are not preserved by fp8 towers (agreement with the oracle and with the bf16 towers is printed, and must be far above
-    chance - 1 / 16384 - because the codebook is coarse against the tokens' error)."""
+    Stated tolerance (e4m3 keeps 3 mantissa bits, 96 quantised linears in a row): pre-quantisation tokens z within 0.20 relative
+    (Frobenius) of the fp32 oracle (measured 0.111; the bf16 towers 0.019), decoder reconstruction of the ORACLE's codes within 0.15
+    relative (measured 0.118; bf16 0.020); at least 60 % of the token indices equal to the fp32 oracle's (measured 81.9 %; bf16 towers
+    96.8 %; MX against bf16 towers 82.6 %): a 16384-entry L2 codebook is far more forgiving than FSQ's rounding boundaries."""
     from types import SimpleNamespace
     from oracle import vq_oracle as V
     n_entries, width, count, shape = 16384, 64, 1024, (32, 256, 256)
@@ -666,6 +666,6 @@ def test_base_cfg5_mx_fp8_towers_with_the_16384x64_codebook_on_one_full_size_cli
     print(f"base cfg5, one 32x256x256 clip: z rel. error bf16 {res[False]['z']:.4f} | mx-fp8 {res['mx']['z']:.4f}; decoder rel. error on the oracle's codes "
           f"bf16 {res[False]['dec']:.4f} | mx-fp8 {res['mx']['dec']:.4f}; indices equal to the fp32 oracle's: bf16 {agree(res[False]['idx'], idx_ref):.3f} | "
           f"mx-fp8 {agree(res['mx']['idx'], idx_ref):.3f}; mx-fp8 vs bf16 towers {agree(res['mx']['idx'], res[False]['idx']):.3f}")
-    assert res["mx"]["z"] < 0.30 and res["mx"]["dec"] < 0.15
-    assert res[False]["z"] < 0.08
-    assert agree(res["mx"]["idx"], idx_ref) > 0.05
+    assert res["mx"]["z"] < 0.20 and res["mx"]["dec"] < 0.15
+    assert res[False]["z"] < 0.05
+    assert agree(res["mx"]["idx"], idx_ref) > 0.60 and agree(res[False]["idx"], idx_ref) > 0.90
