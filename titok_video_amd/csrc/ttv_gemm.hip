@@ -43,6 +43,9 @@ struct GemmDev {
   const float* row_scale;   // optional [M]: acc rows are multiplied by it first (folded pre-norm of the generic-K kernels)
   const int* rope_ids; const float* rope_base;   // optional: rotary factors by position id (k256 QKV kernel; see ttv_batch.rope_ids)
   const float* x_scale; const float* w_scale;   // fp8 operands: per-token / per-weight-row dequantisation factors (k_gemm_fp8_dma; either may be NULL with MX)
+  // EPI_RESID_NORM extras (training tape, round 4): the pre-norm sum in fp32, and a SECOND RMSNorm of the row just produced
+  float* sum_f32; int ld_sum;                   // optional [M, N] fp32: alpha * resid + acc (what the post-norm's backward needs)
+  void* y2; int ldy2; const float* norm_gain2;  // optional [M, N] dtype: RMSNorm(y) * norm_gain2 with y as stored (rounded): the next pre-norm's output
   int split3;                                   // fp32 kernel: w is the split-bf16 image (hi | lo per 16-byte chunk), products in three bf16 passes
   const uint8_t* x_mx; const uint8_t* w_mx;     // MX block scales (E8M0, k_quant_mx_fp8's layout), ld_mx bytes per row
   int ld_mx;
@@ -1367,15 +1370,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_t
     const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
     const bool odd = kq & 1;
     bf16_t* yrow = (bf16_t*)p.y + (size_t)t * p.ldy;
+    if (p.sum_f32 && tvalid) {          // training tape: the pre-norm sum (uniform branch)
+      float* srow_ = p.sum_f32 + (size_t)t * p.ld_sum + kq * 4;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(srow_ + i * 16) = acc[i];
+    }
+    float ss2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_gain + i * 16 + kq * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[i][e] = round_to<bf16_t>(acc[i][e] * rstd * g[e]);     // the value that is stored
+        ss2 = fmaf(acc[i][e], acc[i][e], ss2);
+      }
+    }
 #pragma unroll
     for (int ip = 0; ip < 8; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.norm_gain + i0 * 16 + kq * 4);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.norm_gain + i1 * 16 + kq * 4);
-      f32x4 y0, y1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][e] * rstd * g0[e]; y1[e] = acc[i1][e] * rstd * g1[e]; }
-      const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
+      const uint2 p0 = pack_bf16x4(acc[i0]), p1 = pack_bf16x4(acc[i1]);
       const uint2 send = odd ? p0 : p1;
       uint2 recv;
       recv.x = __shfl_xor(send.x, 16, 64);
@@ -1383,6 +1396,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_t
       const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
       const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
       if (tvalid && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = out;
+    }
+    if (p.y2) {                         // the NEXT pre-norm of the row just written (training tape: xn of the following sub-layer)
+      ss2 += __shfl_xor(ss2, 16, 64);
+      ss2 += __shfl_xor(ss2, 32, 64);
+      const float rstd2 = 1.0f / sqrtf(ss2 * (1.0f / 256.0f) + p.eps);
+      bf16_t* y2row = (bf16_t*)p.y2 + (size_t)t * p.ldy2;
+#pragma unroll
+      for (int ip = 0; ip < 8; ++ip) {
+        const int i0 = 2 * ip, i1 = 2 * ip + 1;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.norm_gain2 + i0 * 16 + kq * 4);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.norm_gain2 + i1 * 16 + kq * 4);
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][e] * rstd2 * g0[e]; y1[e] = acc[i1][e] * rstd2 * g1[e]; }
+        const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
+        const uint2 send = odd ? p0 : p1;
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 16, 64);
+        recv.y = __shfl_xor(send.y, 16, 64);
+        const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
+        if (tvalid && !(p.debug & 1)) *reinterpret_cast<uint4*>(y2row + start) = out;
+      }
     }
   }
 #undef WROWN
@@ -1499,20 +1535,34 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
   }
   __syncthreads();
   const bool odd = kq & 1;
+  float ssq2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int tl = j * 16 + l15, t = tbase + tl;
     const float tot = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
     const float rstd = 1.0f / sqrtf(tot * (1.0f / 256.0f) + p.eps);
+    if (p.sum_f32 && t < p.M) {         // training tape: the pre-norm sum (uniform branch)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(p.sum_f32 + (size_t)t * p.ld_sum + wave * 64 + i * 16 + kq * 4) = acc[i][j];
+    }
+    float ss2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_gain + wave * 64 + i * 16 + kq * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[i][j][e] = round_to<bf16_t>(acc[i][j][e] * rstd * g[e]);   // the value that is stored
+        ss2 = fmaf(acc[i][j][e], acc[i][j][e], ss2);
+      }
+    }
+    ss2 += __shfl_xor(ss2, 16, 64);
+    ss2 += __shfl_xor(ss2, 32, 64);
+    ssq2[j] = ss2;
 #pragma unroll
     for (int ip = 0; ip < 2; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       const int f0 = wave * 64 + i0 * 16 + kq * 4, f1 = wave * 64 + i1 * 16 + kq * 4;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.norm_gain + f0), g1 = *reinterpret_cast<const f32x4*>(p.norm_gain + f1);
-      f32x4 y0, y1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][j][e] * rstd * g0[e]; y1[e] = acc[i1][j][e] * rstd * g1[e]; }
-      const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
+      const uint2 p0 = pack_bf16x4(acc[i0][j]), p1 = pack_bf16x4(acc[i1][j]);
       const uint2 send = odd ? p0 : p1;
       uint2 recv;
       recv.x = __shfl_xor(send.x, 16, 64);
@@ -1520,6 +1570,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
       const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
       const int start = odd ? f1 - 4 : f0;
       if (t < p.M && !(p.debug & 1)) *reinterpret_cast<uint4*>((bf16_t*)p.y + (size_t)t * p.ldy + start) = out;
+    }
+  }
+  if (p.y2) {                           // the NEXT pre-norm of the rows just written: a second exchange of the four waves' partial sums
+    __syncthreads();                    // every wave has read `red`
+    if (kq == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][j * 16 + l15] = ssq2[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tl = j * 16 + l15, t = tbase + tl;
+      const float tot2 = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+      const float rstd2 = 1.0f / sqrtf(tot2 * (1.0f / 256.0f) + p.eps);
+#pragma unroll
+      for (int ip = 0; ip < 2; ++ip) {
+        const int i0 = 2 * ip, i1 = 2 * ip + 1;
+        const int f0 = wave * 64 + i0 * 16 + kq * 4, f1 = wave * 64 + i1 * 16 + kq * 4;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.norm_gain2 + f0), g1 = *reinterpret_cast<const f32x4*>(p.norm_gain2 + f1);
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][j][e] * rstd2 * g0[e]; y1[e] = acc[i1][j][e] * rstd2 * g1[e]; }
+        const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
+        const uint2 send = odd ? p0 : p1;
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 16, 64);
+        recv.y = __shfl_xor(send.y, 16, 64);
+        const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        const int start = odd ? f1 - 4 : f0;
+        if (t < p.M && !(p.debug & 1)) *reinterpret_cast<uint4*>((bf16_t*)p.y2 + (size_t)t * p.ldy2 + start) = out;
+      }
     }
   }
 }
@@ -1860,6 +1941,7 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end;
   d.eps = a.eps;
   d.debug = g_ttv_debug;
+  d.sum_f32 = a.sum_f32; d.ld_sum = a.ld_sum; d.y2 = a.y2; d.ldy2 = a.ldy2; d.norm_gain2 = a.norm_gain2;
   d.split3 = (a.split3 && a.dtype == TTV_F32) ? 1 : 0;
   d.x_mx = d.w_mx = nullptr; d.ld_mx = 0;
   d.norm_gain = a.norm_gain;
@@ -1913,6 +1995,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
       TTV_CHECK_ARG(ttvk_gemm_supports_resid_norm(a.dtype, a.N, a.K), "gemm: fused residual+norm needs bf16 and N == 256");
       TTV_CHECK_ARG(a.resid && a.norm_gain && a.ldr % 4 == 0 && a.ldw >= 256, "gemm: residual / gain missing");
       TTV_CHECK_ARG(a.y != a.x, "gemm: fused residual+norm output must not alias the GEMM input");
+      TTV_CHECK_ARG(!a.y2 || (a.norm_gain2 && a.ldy2 % 8 == 0 && (uintptr_t)a.y2 % 16 == 0 && a.y2 != a.x), "gemm: second norm output needs its gain, 16-byte rows");
+      TTV_CHECK_ARG(!a.sum_f32 || (a.ld_sum % 4 == 0 && (uintptr_t)a.sum_f32 % 16 == 0), "gemm: fp32 sum output needs 16-byte rows");
       if (a.K == 256) {
         const int n_tiles = ttv_cdiv(a.M, ROW_TT);
         hipLaunchKernelGGL(k_gemm_k256_rownorm, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), 0, s, d, n_tiles);

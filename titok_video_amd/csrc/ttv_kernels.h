@@ -60,6 +60,10 @@ struct GemmArgs {
   int rope_q_end, rope_k_begin, rope_k_end;  // column ranges [0,q_end) and [k_begin,k_end) get rotary
   int dtype;
   const float* norm_gain;          // EPI_RESID_NORM: post-norm gain [N]
+  // EPI_RESID_NORM, optional (training tape): the pre-norm sum alpha * resid + acc in fp32, and RMSNorm(y) * norm_gain2 of the stored
+  // (rounded) row = the next pre-norm's output, so that neither needs a launch of its own
+  float* sum_f32; int ld_sum;
+  void* y2; int ldy2; const float* norm_gain2;
   int split3;                      // fp32 only: w is the split-bf16 image of the weight (ttv_split3_pack) and the products run as three bf16
                                    // MFMA passes (k_gemm_f32<.., SPLIT>)
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)

@@ -4,6 +4,7 @@
 // buffers (atomics in the reduction kernels); activation gradients travel in the compute dtype, the residual-stream
 // gradient in fp32.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "ttv_common.h"
 #include "ttv_kernels.h"
@@ -97,10 +98,16 @@ static int check(const ttv_tower_dims* d, const ttv_batch* b) {
 // ------------------------------------------------------------------------------------------------ forward (tape)
 static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, Tape& t, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
+  // Round 4: where the fused residual + KEEL-norm GEMM applies (bf16, width 256) the post-norm, the fp32 pre-norm sum the backward
+  // needs AND the following pre-norm come out of the GEMM kernel (GemmArgs.sum_f32 / y2): 5 launches per layer instead of 9.
+  // TTV_TRAIN_FUSED_NORMS=0 keeps the unfused sequence (A/B; the tape holds the same tensors either way).
+  static const bool fuse_norms = !(getenv("TTV_TRAIN_FUSED_NORMS") && getenv("TTV_TRAIN_FUSED_NORMS")[0] == '0');
+  bool xn1_ready = false;          // this layer's xn1 was written by the layer below
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
     Tape::L& l = t.l[i];
-    TTV_TRY(ttvk_rmsnorm(t.X[i], dt, dm, nullptr, l.xn1, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+    if (!xn1_ready) TTV_TRY(ttvk_rmsnorm(t.X[i], dt, dm, nullptr, l.xn1, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+    xn1_ready = false;
     GemmArgs a = {};
     a.dtype = dt; a.x = l.xn1; a.ldx = dm; a.w = lw.to_qkv; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = l.qkvg; a.ldy = nq;
     a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
@@ -120,12 +127,17 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     if (i == 0) {
       o.alpha = 1.f; o.y = l.x1; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
+    } else if (fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, dm)) {
+      o.alpha = d->alpha; o.y = l.x1; o.ldy = dm; o.norm_gain = lw.attn_post_ln; o.eps = d->eps;
+      o.sum_f32 = l.y1; o.ld_sum = dm; o.y2 = l.xn2; o.ldy2 = dm; o.norm_gain2 = lw.ffd_norm;
+      TTV_TRY(ttvk_gemm(EPI_RESID_NORM, o, s));
     } else {
       o.alpha = d->alpha; o.y = l.y1; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
       TTV_TRY(ttvk_rmsnorm(l.y1, TTV_F32, dm, nullptr, l.x1, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
     }
-    TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+    if (!(i > 0 && fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, dm)))
+      TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
     GemmArgs f = {};
     if (dt == TTV_BF16) {
       // one launch: u = xn2 W12^T kept for the backward (through `resid`) and h = gelu(gate) * x from the stored values
@@ -142,6 +154,14 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     if (i == 0) {
       f3.alpha = 1.f; f3.y = t.X[i + 1]; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
+    } else if (fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, I)) {
+      f3.alpha = d->alpha; f3.y = t.X[i + 1]; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
+      f3.sum_f32 = l.y2; f3.ld_sum = dm;
+      if (i + 1 < d->layers) {          // the next layer's pre-norm rides along
+        f3.y2 = t.l[i + 1].xn1; f3.ldy2 = dm; f3.norm_gain2 = w->layers[i + 1].pre_ln;
+        xn1_ready = true;
+      }
+      TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
       f3.alpha = d->alpha; f3.y = l.y2; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
