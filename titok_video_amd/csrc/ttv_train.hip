@@ -98,10 +98,12 @@ static int check(const ttv_tower_dims* d, const ttv_batch* b) {
 // ------------------------------------------------------------------------------------------------ forward (tape)
 static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, Tape& t, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
-  // Round 4: where the fused residual + KEEL-norm GEMM applies (bf16, width 256) the post-norm, the fp32 pre-norm sum the backward
-  // needs AND the following pre-norm come out of the GEMM kernel (GemmArgs.sum_f32 / y2): 5 launches per layer instead of 9.
-  // TTV_TRAIN_FUSED_NORMS=0 keeps the unfused sequence (A/B; the tape holds the same tensors either way).
-  static const bool fuse_norms = !(getenv("TTV_TRAIN_FUSED_NORMS") && getenv("TTV_TRAIN_FUSED_NORMS")[0] == '0');
+  // Round 4, OPT-IN (TTV_TRAIN_FUSED_NORMS=1): where the fused residual + KEEL-norm GEMM applies (bf16, width 256) the post-norm, the fp32
+  // pre-norm sum the backward needs AND the following pre-norm come out of the GEMM kernel (GemmArgs.sum_f32 / y2): 5 launches per layer
+  // instead of 9, same tape.  Measured neutral (same box, tools/bench_train.py: 8.234 vs 8.236 ms at 32 clips, 3.47 vs 3.44 ms at 5): the
+  // row-owning GEMM kernels lose against the tiled GEMM + 160-token tiles what the four row kernels cost, and the step is GPU-bound, not
+  // launch-bound - so the proven sequence stays the default.
+  static const bool fuse_norms = getenv("TTV_TRAIN_FUSED_NORMS") && getenv("TTV_TRAIN_FUSED_NORMS")[0] == '1';
   bool xn1_ready = false;          // this layer's xn1 was written by the layer below
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
