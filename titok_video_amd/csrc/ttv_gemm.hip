@@ -1118,11 +1118,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
   float2 rc[4][2], rs[4][2];
   PatchDst pdst[2];
 
-  bf16x8 af[2][4];
+#ifndef K256_DEPTH
+#define K256_DEPTH 2      // A-fragment register buffers: fragments of k-step s + DEPTH - 1 are requested before the MFMAs of step s.
+                          // -DK256_DEPTH=3 (two steps ahead, +12..17 VGPRs, no scratch) measured neutral in a same-box A/B, round 4
+                          // (QKV 35.9 / 36.0 vs 36.2 / 36.4 us on a slow box): the fragment-read latency is not what the loop waits for
+#endif
+  bf16x8 af[K256_DEPTH][4];
   GLDS_PANEL(it0 % n_panels, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
   LOADA(af[0], 0, 0);
+  if (K256_DEPTH == 3) LOADA(af[1], 0, 1);
   for (int it = it0; it < it1; ++it) {
     const int buf = (it - it0) & 1;
     const int tile = it / n_panels, panel = it - tile * n_panels;
@@ -1219,19 +1225,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
     // A fragments double-buffered in registers: the reads of k-step s+1 are issued before the 8 MFMAs of k-step s
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
-      if (s8 + 1 < 8) {
-        const int ch = (s8 + 1) * 4 + kq;
+      constexpr int AH = K256_DEPTH - 1;     // how many k-steps ahead the fragments are requested
+      if (s8 + AH < 8) {
+        const int ch = (s8 + AH) * 4 + kq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int arow = i * 16 + l15;
-          af[(s8 + 1) & 1][i] = __builtin_bit_cast(bf16x8, wl[buf][arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
+          af[(s8 + AH) % K256_DEPTH][i] = __builtin_bit_cast(bf16x8, wl[buf][arow * 32 + ((ch & 16) | ((ch & 15) ^ (arow & 15)))]);
         }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s8 & 1][i], bfr[j][s8], acc[i][j], 0, 0, 0);
-      if (s8 + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s8 % K256_DEPTH][i], bfr[j][s8], acc[i][j], 0, 0, 0);
+      if (s8 + AH < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1239,7 +1246,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
     // the waves then run their epilogues unsynchronised, with the first fragments of the next item already requested
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next panel is in LDS
     __syncthreads();
-    if (it + 1 < it1) LOADA(af[0], buf ^ 1, 0);
+    if (it + 1 < it1) {
+      LOADA(af[0], buf ^ 1, 0);
+      if (K256_DEPTH == 3) LOADA(af[1], buf ^ 1, 1);
+    }
 
     int tok[2];
 #pragma unroll
