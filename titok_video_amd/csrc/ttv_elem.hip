@@ -343,6 +343,15 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ codes, 
 #pragma unroll
           for (int c = 0; c < TTV_MAX_FSQ; ++c)
             if (c < C) h += cz[c] * Cvt<T>::to_f(w[(size_t)f * C + c]);
+        } else if ((C & 3) == 0) {      // wide tokens (the L2 quantiser's 32 / 64): four elements per load, same summation order
+          const T* wrow = w + (size_t)f * C;
+          for (int c = 0; c < C; c += 4) {
+            const f32x4 cv = Vec4<T>::load(crow + c), wv = Vec4<T>::load(wrow + c);
+            h += cv[0] * wv[0];
+            h += cv[1] * wv[1];
+            h += cv[2] * wv[2];
+            h += cv[3] * wv[3];
+          }
         } else {
           for (int c = 0; c < C; ++c) h += Cvt<T>::to_f(crow[c]) * Cvt<T>::to_f(w[(size_t)f * C + c]);
         }
