@@ -301,3 +301,30 @@ def test_base_towers_with_mx_fp8_linears_stay_within_the_stated_tolerance():
     assert not torch.equal(res[False][0], res["mx"][0]) and not torch.equal(res[True][0], res["mx"][0])      # the MX path really ran
     assert float((res["mx"][0] - ref_b).abs().mean()) < 0.30
     assert float((res["mx"][2] - ref_flat).norm() / ref_flat.norm()) < 0.15
+
+
+def test_mx_quantisation_fused_into_the_producers_is_bit_identical():
+    """run_layer_mx writes the block-scaled image of x from the KEEL post-norm kernel and of h from the w12 GEMM's GEGLU epilogue; with
+    ttv_debug_set bit 11 every operand is quantised by a pass of its own.  Same values, same blocks, same rounding: the towers' outputs
+    must be equal bit for bit."""
+    levels = [8, 8, 8, 6, 5]
+    sd = seeded_titok_state(3, "base", "base", gain=3.0)
+    shapes, counts = [(4, 16, 16), (8, 16, 24), (4, 32, 16)], [16, 24, 20]
+    clips = [c.to(DEV, torch.bfloat16) for c in synthetic_clips(shapes, seed=13)]
+    m = TiTok(_base_cfg(levels))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV, torch.bfloat16).eval()
+    m.encoder.fp8_linears = m.decoder.fp8_linears = "mx"
+    outs = []
+    for bit in (0, 2048):
+        _lib.lib().ttv_debug_set(bit)
+        try:
+            with torch.no_grad():
+                z = m.encoder.run(clips, counts, None, None, want_z=True)["z"].clone()
+                recon, info = m(clips, counts)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().ttv_debug_set(0)
+        outs.append((z, [r.clone() for r in recon], info["indices"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

@@ -95,10 +95,17 @@ static int check_dims(const ttv_tower_dims* d, const ttv_batch* b) {
 // input is quantised by k_quant_mx_fp8, the pre-norm gains live in the weight images and the rstd of the pre-norm is the activation's
 // per-row factor in the GEMM epilogue; attention, the KEEL sums and norms stay bf16 / fp32 as in the bf16 tower.
 static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, const ttv_batch* b, const TowerWs& ws, int i, bool& rstd_valid,
-                        bool attn_pipe, hipStream_t s) {
+                        bool& xq_valid, bool attn_pipe, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
+  // Quantisation is fused into the producers where the producer owns whole 32-element blocks (TTV_MX_FUSED_QUANT=0: every operand by a
+  // pass of its own, A/B): the KEEL post-norm kernel writes x also as its block-scaled image (ws.f8 / ws.f8mx), the w12 GEMM's GEGLU
+  // epilogue writes h only as its image (into the bf16 h buffer and the xn buffer, both unused in this mode).  Left as passes: the
+  // attention output (its kernel is untouched) and layer 0's two inputs (no norm kernel in front of them).
+  static const bool fused_env = !(getenv("TTV_MX_FUSED_QUANT") && getenv("TTV_MX_FUSED_QUANT")[0] == '0');
+  const bool fused_q = fused_env && !(g_ttv_debug & 2048);      // ttv_debug_set bit 11: the unfused sequence (tests: both must agree bit for bit)
   if (!rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
-  TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  if (!xq_valid) TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  xq_valid = false;
   GemmArgs a = {};
   a.dtype = dt; a.x = ws.f8; a.ldx = dm; a.w = lw.to_qkv_f8; a.ldw = dm; a.M = L; a.N = nq; a.K = dm; a.y = ws.qkv; a.ldy = nq;
   a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
@@ -112,21 +119,38 @@ static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, co
   o.dtype = dt; o.x = ws.f8; o.ldx = dm; o.w = lw.out_proj_f8; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
   o.alpha = i == 0 ? 1.f : d->alpha; o.y = ws.x; o.ldy = dm;
   TTV_TRY(ttvk_gemm_fp8(EPI_RESID_T, o, nullptr, lw.out_proj_f8_scale, s, ws.f8mx, lw.out_proj_mx));
-  if (i > 0) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, ws.rstd));
-  else TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
-  TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  if (i > 0) {
+    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, ws.rstd, fused_q ? ws.f8 : nullptr,
+                         fused_q ? ws.f8mx : nullptr));
+    if (!fused_q) TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  } else {
+    TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
+    TTV_TRY(ttvk_quant_mx_fp8(ws.x, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  }
   GemmArgs f = {};
   f.dtype = dt; f.x = ws.f8; f.ldx = dm; f.w = lw.w12_f8; f.ldw = dm; f.M = L; f.N = I; f.K = dm; f.y = ws.h; f.ldy = I;
+  char* const hq = ws.h;          // fp8 image of h [L, I] in the bf16 h buffer; its scales in the xn buffer (L * dm * 2 bytes >= L * 4 * nkp(I))
+  char* const hq_mx = ws.xn;
+  const bool h_fused = fused_q && (int64_t)ttvk_mx_scale_ld(I) <= (int64_t)dm * 2;
+  if (h_fused) { f.yq = hq; f.yq_mx = hq_mx; }
   TTV_TRY(ttvk_gemm_fp8(EPI_GEGLU, f, ws.rstd, lw.w12_f8_scale, s, ws.f8mx, lw.w12_mx));
-  TTV_TRY(ttvk_quant_mx_fp8(ws.h, dt, I, ws.f8, I, ws.f8mx, nullptr, L, I, s));
   GemmArgs f3 = {};
-  f3.dtype = dt; f3.x = ws.f8; f3.ldx = I; f3.w = lw.w3_f8; f3.ldw = I; f3.M = L; f3.N = dm; f3.K = I; f3.resid = ws.x; f3.ldr = dm;
+  if (h_fused) {
+    f3.x = hq;
+  } else {
+    TTV_TRY(ttvk_quant_mx_fp8(ws.h, dt, I, ws.f8, I, ws.f8mx, nullptr, L, I, s));
+    f3.x = ws.f8;
+  }
+  f3.dtype = dt; f3.ldx = I; f3.w = lw.w3_f8; f3.ldw = I; f3.M = L; f3.N = dm; f3.K = I; f3.resid = ws.x; f3.ldr = dm;
   f3.alpha = i == 0 ? 1.f : d->alpha; f3.y = ws.x; f3.ldy = dm;
-  TTV_TRY(ttvk_gemm_fp8(EPI_RESID_T, f3, nullptr, lw.w3_f8_scale, s, ws.f8mx, lw.w3_mx));
+  TTV_TRY(ttvk_gemm_fp8(EPI_RESID_T, f3, nullptr, lw.w3_f8_scale, s, h_fused ? hq_mx : ws.f8mx, lw.w3_mx));
   rstd_valid = false;
   if (i > 0) {
-    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, ws.rstd));
+    // the next layer's to_qkv operand rides along (the caller only uses it when the next layer runs this path too)
+    TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, ws.rstd, fused_q ? ws.f8 : nullptr,
+                         fused_q ? ws.f8mx : nullptr));
     rstd_valid = true;
+    xq_valid = fused_q;
   }
   return TTV_OK;
 }
@@ -141,16 +165,18 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   const int nq = 2 * dm + 2 * g;
   bool qkv_ready = false;   // the previous layer's tail kernel already produced this layer's rotated qkv
   bool rstd_valid = false;  // ws.rstd holds rsqrt(mean(x^2) + eps) of the current ws.x (written by the kernel that produced x)
+  bool xq_valid = false;    // ws.f8 / ws.f8mx hold the block-scaled e4m3 image of the current ws.x (run_layer_mx)
   static const bool attn_pipe = getenv("TTV_ATTN_PIPE") && getenv("TTV_ATTN_PIPE")[0] == '1';   // opt-in pipelined attention kernel
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
     static const bool keel_f32 = getenv("TTV_KEEL_F32SUM") && getenv("TTV_KEEL_F32SUM")[0] == '1';
     if (dt == TTV_BF16 && dm != 256 && dm % 128 == 0 && d->inner % 128 == 0 && !keel_f32 && lw.to_qkv_f8 && lw.to_qkv_mx && lw.w12_f8 && lw.w12_mx &&
         lw.out_proj_f8 && lw.out_proj_mx && lw.w3_f8 && lw.w3_mx) {
-      TTV_TRY(run_layer_mx(d, lw, b, ws, i, rstd_valid, attn_pipe, s));
+      TTV_TRY(run_layer_mx(d, lw, b, ws, i, rstd_valid, xq_valid, attn_pipe, s));
       qkv_ready = false;
       continue;
     }
+    xq_valid = false;
     // ---- attention sub-layer (transformer.py:85-104) ----
     // mixed bf16 / fp8 (config #5): the pre-norm output is quantised to e4m3 per token (into the xn buffer: L x dm bytes of values,
     // then L fp32 scales) and the projection runs on the fp8 MFMA; everything downstream is unchanged

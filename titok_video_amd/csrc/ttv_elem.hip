@@ -8,6 +8,23 @@
 #define ROWS_PER_BLOCK 4
 #define MAX_ITERS 4  // width <= 64 lanes * 4 elems * 4 iters = 1024
 
+// One lane's four values of a 32-element MX block (8 consecutive lanes): block maximum by three xor shuffles, E8M0 byte of the smallest
+// power of two >= max / 448, the four e4m3 bytes.  Bit-identical to k_quant_mx_fp8 (no row factor) on the same values.
+__device__ __forceinline__ int mx_quant4(const f32x4 y, int& byte) {
+  float a = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+  a = fmaxf(a, __shfl_xor(a, 1));
+  a = fmaxf(a, __shfl_xor(a, 2));
+  a = fmaxf(a, __shfl_xor(a, 4));
+  const uint32_t tb = __float_as_uint(a * (1.0f / 448.0f));
+  byte = (int)((tb >> 23) & 0xFF) + ((tb & 0x7FFFFF) ? 1 : 0);
+  byte = a > 0.f ? (byte < 1 ? 1 : (byte > 254 ? 254 : byte)) : 127;
+  const float inv_blk = __uint_as_float((uint32_t)(254 - byte) << 23);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0] * inv_blk, y[1] * inv_blk, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2] * inv_blk, y[3] * inv_blk, w, true);
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // RMSNorm with optional row gather/scatter maps.
 // ------------------------------------------------------------------------------------------------
@@ -15,7 +32,10 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int ld_in, const int* __restrict__ src_rows,
                                                  TO* __restrict__ out, int ld_out, const int* __restrict__ dst_rows,
                                                  const float* __restrict__ gain, int rows, int d, float eps,
-                                                 float* __restrict__ next_rstd) {
+                                                 float* __restrict__ next_rstd, uint8_t* __restrict__ mx_q = nullptr,
+                                                 uint8_t* __restrict__ mx_s = nullptr, int mx_ld = 0, int mx_nkp = 0) {
+  // mx_q / mx_s (round 4, config #5): the row as STORED, additionally as block-scaled e4m3 (k_quant_mx_fp8's output for that row,
+  // bit for bit) - the next linear's fp8 operand without a quantisation pass of its own.  Needs d % 128 == 0.
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * ROWS_PER_BLOCK + wave;
   if (r >= rows) return;
@@ -46,6 +66,16 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int 
       if (next_rstd) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float w = round_to<TO>(o[e]); so = fmaf(w, w, so); }
+      }
+      if (mx_q) {        // d % 128 == 0: lanes leave in 32-lane halves, never inside an 8-lane block
+        const f32x4 yr = {round_to<TO>(o[0]), round_to<TO>(o[1]), round_to<TO>(o[2]), round_to<TO>(o[3])};
+        int byte;
+        const int w8 = mx_quant4(yr, byte);
+        *reinterpret_cast<int*>(mx_q + (size_t)dr * d + c) = w8;
+        if ((lane & 7) == 0) {
+          const int b = c >> 5;
+          mx_s[(size_t)dr * mx_ld + (b & 3) * mx_nkp + (b >> 2)] = (uint8_t)byte;
+        }
       }
     }
   }
@@ -88,23 +118,25 @@ int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, i
 
 template <typename TI, typename TO>
 static int launch_rmsnorm(const void* in, int ld_in, const int* src_rows, void* out, int ld_out, const int* dst_rows,
-                          const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd) {
+                          const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s) {
   if (rows == 0) return TTV_OK;
   TtvProfScope prof(TTV_KC_RMSNORM, s);
+  const int nkp = (d / 128 + 3) / 4 * 4;
   hipLaunchKernelGGL((k_rmsnorm<TI, TO>), dim3(ttv_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, s, (const TI*)in, ld_in,
-                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps, next_rstd);
+                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps, next_rstd, (uint8_t*)mx_q, (uint8_t*)mx_s, 4 * nkp, nkp);
   TTV_CHECK_LAUNCH("rmsnorm");
   return TTV_OK;
 }
 
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
-                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd) {
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s) {
   TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS, "rmsnorm: width %d must be a multiple of 4 and <= 1024", d);
   TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "rmsnorm: leading dims must be multiples of 4");
-  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
-  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
-  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
-  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd);
+  TTV_CHECK_ARG(!mx_q || (mx_s && d % 128 == 0 && (uintptr_t)mx_q % 4 == 0), "rmsnorm: the block-scaled fp8 side output needs its scale buffer and width %% 128 == 0");
+  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
+  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
   ttv_set_error("rmsnorm: bad dtypes %d %d", in_dtype, out_dtype);
   return TTV_ERR_INVALID;
 }

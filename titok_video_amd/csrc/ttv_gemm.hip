@@ -49,6 +49,7 @@ struct GemmDev {
   int split3;                                   // fp32 kernel: w is the split-bf16 image (hi | lo per 16-byte chunk), products in three bf16 passes
   const uint8_t* x_mx; const uint8_t* w_mx;     // MX block scales (E8M0, k_quant_mx_fp8's layout), ld_mx bytes per row
   int ld_mx;
+  uint8_t* yq; uint8_t* yq_mx; int ld_yq_mx, yq_nkp;   // EPI_GEGLU of the MX kernel: h leaves as block-scaled e4m3 [M, N] + scales instead of bf16
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
 };
 
@@ -1018,6 +1019,44 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
       for (int e = 0; e < 4; ++e) acc[i][j][e] *= sx[j] * sw4[e];
   }
   if (DUAL) {
+    if (MX && p.yq) {
+      // GEGLU output straight into the NEXT linear's operand format (round 4): a wave's two 16-feature tiles of a token are exactly one
+      // 32-element MX block of h - spread over the four lane groups kq -, so the block maximum is two xor shuffles away, and the
+      // bf16 copy of h (151 MB at the base shape) and its quantisation pass disappear.  Values are rounded to bf16 first: the image is
+      // bit for bit what k_quant_mx_fp8 makes of the bf16 h the plain epilogue stores.
+      if (p.debug & 1) return;
+      const int blk = (fbase + wf * 32) >> 5;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x4 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          h0[e] = round_to<bf16_t>(geglu_fast(acc[2][j][e], acc[0][j][e]));
+          h1[e] = round_to<bf16_t>(geglu_fast(acc[3][j][e], acc[1][j][e]));
+        }
+        float a = fmaxf(fmaxf(fmaxf(fabsf(h0[0]), fabsf(h0[1])), fmaxf(fabsf(h0[2]), fabsf(h0[3]))),
+                        fmaxf(fmaxf(fabsf(h1[0]), fabsf(h1[1])), fmaxf(fabsf(h1[2]), fabsf(h1[3]))));
+        a = fmaxf(a, __shfl_xor(a, 16, 64));
+        a = fmaxf(a, __shfl_xor(a, 32, 64));
+        const uint32_t tb = __float_as_uint(a * (1.0f / 448.0f));
+        int byte = (int)((tb >> 23) & 0xFF) + ((tb & 0x7FFFFF) ? 1 : 0);
+        byte = a > 0.f ? (byte < 1 ? 1 : (byte > 254 ? 254 : byte)) : 127;
+        const float inv = __uint_as_float((uint32_t)(254 - byte) << 23);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(h0[0] * inv, h0[1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(h0[2] * inv, h0[3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(h1[0] * inv, h1[1] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(h1[2] * inv, h1[3] * inv, w1, true);
+        const int t = tok[j];
+        if (t < p.M && fbase + wf * 32 + 32 <= p.N) {
+          uint8_t* row = p.yq + (size_t)t * p.N + fbase + wf * 32 + kq * 4;
+          *reinterpret_cast<int*>(row) = w0;
+          *reinterpret_cast<int*>(row + 16) = w1;
+          if (kq == 0) p.yq_mx[(size_t)t * p.ld_yq_mx + (blk & 3) * p.yq_nkp + (blk >> 2)] = (uint8_t)byte;
+        }
+      }
+      return;
+    }
     int feat[2];
     f32x4 ax[2][NJ], ag[2][NJ];
 #pragma unroll
@@ -1909,6 +1948,10 @@ int ttvk_gemm_fp8(GemmEpilogue epi, const GemmArgs& a, const float* x_scale, con
   d.rope_q_end = a.rope_q_end; d.rope_k_begin = a.rope_k_begin; d.rope_k_end = a.rope_k_end; d.eps = a.eps; d.debug = g_ttv_debug;
   d.x_scale = x_scale; d.w_scale = w_scale;
   d.x_mx = (const uint8_t*)x_mx; d.w_mx = (const uint8_t*)w_mx; d.ld_mx = 4 * ((a.K / 128 + 3) / 4 * 4);
+  if (a.yq) {
+    TTV_CHECK_ARG(mx && epi == EPI_GEGLU && a.yq_mx && a.N % 128 == 0 && (uintptr_t)a.yq % 4 == 0, "gemm_fp8: the fp8 GEGLU output needs block-scaled operands, its scale buffer and N %% 128 == 0");
+    d.yq = (uint8_t*)a.yq; d.yq_mx = (uint8_t*)a.yq_mx; d.yq_nkp = (a.N / 128 + 3) / 4 * 4; d.ld_yq_mx = 4 * d.yq_nkp;
+  }
   if (epi == EPI_QKV_ROPE) TTV_CHECK_ARG(a.rope_cs && a.rope_q_end % 128 == 0 && a.rope_k_begin % 128 == 0 && a.rope_k_end % 128 == 0, "gemm_fp8: rotary ranges must be multiples of 128 columns");
   const int ft = (epi == EPI_GEGLU) ? 64 : TF;
   const int nf = ttv_cdiv(d.N, ft), nt = ttv_cdiv(d.M, TT), nt160 = ttv_cdiv(d.M, 160);

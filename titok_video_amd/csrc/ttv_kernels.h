@@ -7,7 +7,8 @@
 
 // ---- ttv_elem.hip ----
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
-                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd = nullptr);
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd = nullptr,
+                 void* mx_q = nullptr, void* mx_s = nullptr);   // mx_q / mx_s: the stored row also as block-scaled e4m3 [rows, d] + its E8M0 scales
 int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, int d, float eps, hipStream_t s);
 int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* mask_token,
                          const float* gain, float eps, hipStream_t s);
@@ -64,6 +65,8 @@ struct GemmArgs {
   // (rounded) row = the next pre-norm's output, so that neither needs a launch of its own
   float* sum_f32; int ld_sum;
   void* y2; int ldy2; const float* norm_gain2;
+  void* yq; void* yq_mx;           // ttvk_gemm_fp8 with block scales, EPI_GEGLU: the output leaves as block-scaled e4m3 [M, N] (ld N) + E8M0 scales
+                                   // (k_quant_mx_fp8's layout for width N) instead of bf16 y - the next linear's operand, no pass of its own
   int split3;                      // fp32 only: w is the split-bf16 image of the weight (ttv_split3_pack) and the products run as three bf16
                                    // MFMA passes (k_gemm_f32<.., SPLIT>)
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
