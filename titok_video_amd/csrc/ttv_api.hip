@@ -111,10 +111,16 @@ static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, co
   a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
   TTV_TRY(ttvk_gemm_fp8(EPI_QKV_ROPE, a, ws.rstd, lw.to_qkv_f8_scale, s, ws.f8mx, lw.to_qkv_mx));
   const bool q_scaled = lw.qkv_q_prescaled != 0;
-  TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
-                         TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
-                             (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
-  TTV_TRY(ttvk_quant_mx_fp8(ws.ao, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  if (fused_q && q_scaled && !b->qblocks_paired && !attn_pipe && d->head_dim == 64) {
+    // the attention epilogue writes out_proj's operand itself (no bf16 output, no pass over it); ws.f8 is free: the qkv GEMM has read it
+    TTV_TRY(ttvk_attention_mxout(ws.qkv, nq, ws.f8, ws.f8mx, (int)ttvk_mx_scale_ld(dm), b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads,
+                                 d->kv_heads, s));
+  } else {
+    TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
+                           TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
+                               (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
+    TTV_TRY(ttvk_quant_mx_fp8(ws.ao, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
+  }
   GemmArgs o = {};
   o.dtype = dt; o.x = ws.f8; o.ldx = dm; o.w = lw.out_proj_f8; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
   o.alpha = i == 0 ? 1.f : d->alpha; o.y = ws.x; o.ldy = dm;

@@ -105,7 +105,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 //   * the epilogue uses v_rcp_f32 for 1/l and the sigmoid (a full-precision division is ~10 instructions per element and the
 //     epilogue was a quarter of the wave's vector instructions) and stores 16 bytes per lane (lanes l, l+32 exchange 8-byte
 //     groups with v_permlane32_swap).
-template <bool GATE, int NE, bool PRE, bool TAPE>
+// MXO (round 4, config #5): the output leaves ONLY as the block-scaled e4m3 operand of out_proj - `out_raw` then points at the fp8 image
+// [L, d_model], `lse_out` at its E8M0 scales (k_quant_mx_fp8's layout; lse_out[0 .. ] reinterpreted, `ldo` = bytes of scales per row) -:
+// a 32-element block of a row is one d-half of one head, held by the two lanes (r, 0), (r, 1) of a query, so its maximum is one
+// lane exchange away; the bf16 output and the quantisation pass over it disappear.  The loop is the same code as the plain instantiation.
+template <bool GATE, int NE, bool PRE, bool TAPE, bool MXO = false>
 __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const bf16_t* __restrict__ qkvg, int ld, bf16_t* __restrict__ out, int ldo,
                                                            const int* __restrict__ cu, const int* __restrict__ qblocks, int n_entries,
                                                            int d_model, int gqa, int rep, float c_exp /* scale*log2(e) */,
@@ -574,7 +578,56 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
   if (!live) return;      // NE == 2 only
   if (TAPE && lse_out && qrow < S && h == 0)   // natural-log LSE of the scaled scores (training tape): scale*max + ln(sum)
     lse_out[(size_t)(s0 + qrow) * (d_model >> 6) + head] = m_run * (c_exp * 0.69314718055994530942f) + __logf(l_tot);
-  {
+  if constexpr (MXO) {
+    uint8_t* const oq = reinterpret_cast<uint8_t*>(out_raw) + (size_t)(s0 + qrc) * d_model + head * 64;
+    uint8_t* const omx = reinterpret_cast<uint8_t*>(lse_out) + (size_t)(s0 + qrc) * ldo;
+    const int nkp = ldo >> 2;
+    const bf16_t* grow = gbase + (size_t)qrc * ld;
+    const bool store = qrow < S;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x4 v[4];
+      float amax = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        v[g] = (f32x4){o_acc[dt][4 * g] * inv_l, o_acc[dt][4 * g + 1] * inv_l, o_acc[dt][4 * g + 2] * inv_l, o_acc[dt][4 * g + 3] * inv_l};
+        if (GATE) {
+          const f32x4 gt = Vec4<bf16_t>::load(grow + d0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g][e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gt[e] * -1.44269504088896340736f));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[g][e] = round_to<bf16_t>(v[g][e]);            // the value the bf16 kernel stores: the image equals k_quant_mx_fp8 of that output
+          amax = fmaxf(amax, fabsf(v[g][e]));
+        }
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const uint32_t tb = __float_as_uint(amax * (1.0f / 448.0f));
+      int byte = (int)((tb >> 23) & 0xFF) + ((tb & 0x7FFFFF) ? 1 : 0);
+      byte = amax > 0.f ? (byte < 1 ? 1 : (byte > 254 ? 254 : byte)) : 127;
+      const float inv = __uint_as_float((uint32_t)(254 - byte) << 23);
+      int w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int t = 0;
+        t = __builtin_amdgcn_cvt_pk_fp8_f32(v[g][0] * inv, v[g][1] * inv, t, false);
+        t = __builtin_amdgcn_cvt_pk_fp8_f32(v[g][2] * inv, v[g][3] * inv, t, true);
+        w[g] = t;
+      }
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        // as the bf16 stores: lane (r, 0) ends with the groups 2gp of both lanes = 8 consecutive features, lane (r, 1) with the groups 2gp + 1
+        const auto sx = __builtin_amdgcn_permlane32_swap((unsigned)w[2 * gp], (unsigned)w[2 * gp + 1], false, false);
+        if (store) *reinterpret_cast<uint2*>(oq + dt * 32 + 16 * gp + 8 * h) = make_uint2(sx[0], sx[1]);
+      }
+      if (store && h == 0) {
+        const int blk = head * 2 + dt;
+        omx[(blk & 3) * nkp + (blk >> 2)] = (uint8_t)byte;
+      }
+    }
+  } else {
     // Every lane computes (rows past the end are clamped for the gate load), lanes exchange, rows < S store.  Lanes (r, 0) and
     // (r, 1) hold the 4-feature groups 8g + 0..3 and 8g + 4..7 of a row: for each pair of groups (g, g + 1) one
     // v_permlane32_swap per dword leaves lane (r, 0) with features 8g .. 8g + 7 and lane (r, 1) with 8(g+1) .. 8(g+1) + 7:
@@ -1448,6 +1501,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
         *reinterpret_cast<f32x4*>(orow + d0) = v;
       }
   }
+}
+
+// Attention whose gated output leaves only as the block-scaled e4m3 operand of out_proj (k_attn_bf16<.., MXO>): bf16 inputs with
+// pre-scaled q, unpaired table, sigmoid gate.  out_q [L, d_model] bytes, out_mx [L, ld_mx] E8M0 scales (ttvk_mx_scale_ld(d_model)).
+int ttvk_attention_mxout(const void* qkvg, int ld, void* out_q, void* out_mx, int ld_mx, const int* cu_seqlens, const int* qblocks,
+                         int n_qblocks, int q_heads, int kv_heads, hipStream_t s) {
+  if (n_qblocks == 0) return TTV_OK;
+  TTV_CHECK_ARG(kv_heads > 0 && q_heads % kv_heads == 0, "attention_mxout: q_heads %% kv_heads");
+  const int d_model = q_heads * 64, gqa = kv_heads * 64, rep = q_heads / kv_heads;
+  TTV_CHECK_ARG(ld >= 2 * d_model + 2 * gqa && ld % 8 == 0 && d_model % 128 == 0 && ld_mx == (int)(4 * ((d_model / 128 + 3) / 4 * 4)),
+                "attention_mxout: bad leading dims (d_model %% 128, ld_mx = 4 * round_up(d_model / 128, 4))");
+  TTV_CHECK_ARG(qkvg && out_q && out_mx && (uintptr_t)qkvg % 16 == 0 && (uintptr_t)out_q % 8 == 0, "attention_mxout: null / unaligned pointers");
+  static const float defer_thr = getenv("TTV_ATTN_THR") ? (float)atof(getenv("TTV_ATTN_THR")) : ATTN_DEFER_THR;
+  TtvProfScope prof(TTV_KC_ATTENTION, s);
+  hipLaunchKernelGGL((k_attn_bf16<true, 1, true, false, true>), dim3(n_qblocks), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (bf16_t*)nullptr, ld_mx,
+                     cu_seqlens, qblocks, n_qblocks, d_model, gqa, rep, 1.0f, (float*)out_mx, (bf16_t*)out_q, defer_thr, g_ttv_stamps);
+  TTV_CHECK_LAUNCH("attention_mxout");
+  return TTV_OK;
 }
 
 // flags: bit 0 (TTV_ATTN_GATE) multiply by sigmoid(gate); bit 1 (TTV_ATTN_PAIRED) the table is paired (see k_attn_bf16, NE = 2)

@@ -96,6 +96,9 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
                    int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out = nullptr,
                    void* out_raw = nullptr);
 
+int ttvk_attention_mxout(const void* qkvg, int ld, void* out_q, void* out_mx, int ld_mx, const int* cu_seqlens, const int* qblocks,
+                         int n_qblocks, int q_heads, int kv_heads, hipStream_t s);
+
 // ---- ttv_attn64.hip ----
 int ttvk_attention64(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* items, int n_items, int q_heads,
                      int kv_heads, int flags, hipStream_t s);
