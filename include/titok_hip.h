@@ -209,6 +209,8 @@ int ttv_decoder_embed(const void* codes, int token_size, const void* w, const vo
                                 slower than the plain loop, see ttv_attn.hip; the towers set it under the environment switch TTV_ATTN_PIPE=1) */
 #define TTV_ATTN_SPLIT3 32   /* fp32: the split-bf16 ("three-pass") kernel - operands hi + lo in bf16, three bf16 MFMA passes per product, fp32
                                 softmax and accumulation (~2^-17 relative per product); the towers set it with ttv_tower_weights.f32_split3 */
+#define TTV_ATTN_SPLIT_OUT 64 /* with TTV_ATTN_SPLIT3: the output is written as the split image of the following linear's operand (ttv_split3_pack's
+                                format, same bytes as the fp32 output) */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 /* The same operator (transformer.py:100,103) on the 64-query-rows-per-wave kernel: bf16, head_dim 64, q pre-scaled (flags must carry

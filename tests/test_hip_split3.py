@@ -173,3 +173,27 @@ def test_split3_encoder_mixed_shapes_against_the_oracle():
     model.train()
     with pytest.raises(RuntimeError):
         model([c.to(DEV).requires_grad_(True) for c in clips_cpu], counts)
+
+
+def test_split_images_written_by_the_producers_change_no_bit():
+    """The split towers' norm kernels, attention epilogue and GEGLU epilogue write the next linear's operand as its split image (same bytes
+    as the fp32 tensor); with ttv_debug_set bit 12 the activations stay fp32 and the GEMM's staging threads split them.  Same values,
+    same split: the encoder's tokens must be equal bit for bit."""
+    levels = [7, 5, 5, 5, 5]
+    sd = seeded_titok_state(0)
+    shapes, counts = [(8, 32, 48), (4, 16, 16), (16, 64, 64)], [17, 1, 128]
+    clips = [c.to(DEV) for c in synthetic_clips(shapes, seed=42)]
+    model = TiTok(_cfg(levels))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV, torch.float32).eval().set_index_exact("split3")
+    outs = []
+    for bit in (0, 4096):
+        L().ttv_debug_set(bit)
+        try:
+            with torch.no_grad():
+                z = model.encoder.run(clips, counts, None, None, want_z=True)["z"].clone()
+            torch.cuda.synchronize()
+        finally:
+            L().ttv_debug_set(0)
+        outs.append(z)
+    assert torch.equal(outs[0], outs[1])

@@ -168,6 +168,8 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   // pre-norm gains folded into the weight (to_qkv_pn / w12_pn) with the row statistic applied to the GEMM's output rows: the wide bf16
   // towers, and the split-bf16 towers of any width (their weights are repacked anyway; the exact-fp32 towers keep the reference's order)
   const bool gen_ok = (dt == TTV_BF16 && dm != 256) || split3;
+  static const bool s3img_env = !(getenv("TTV_SPLIT3_IMAGES") && getenv("TTV_SPLIT3_IMAGES")[0] == '0');
+  const int s3img = (split3 && s3img_env && !(g_ttv_debug & 4096)) ? 1 : 0;     // ttv_debug_set bit 12: fp32 activations, split inside the GEMMs (tests)
   const int nq = 2 * dm + 2 * g;
   bool qkv_ready = false;   // the previous layer's tail kernel already produced this layer's rotated qkv
   bool rstd_valid = false;  // ws.rstd holds rsqrt(mean(x^2) + eps) of the current ws.x (written by the kernel that produced x)
@@ -202,9 +204,11 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       // stand-alone RMSNorm launch, no normalised copy of x
       const bool fold_gen = gen_ok && lw.to_qkv_pn;
       if (fold_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
-      if (!fold_qkv && !fold_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s));
+      // split-bf16 towers: the normalised row is written as the projection's split image (its producer splits it once, the GEMM's
+      // staging threads copy bytes); TTV_SPLIT3_IMAGES=0 keeps fp32 activations and the split in the GEMM (A/B)
+      if (!fold_qkv && !fold_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s, nullptr, nullptr, nullptr, s3img));
       GemmArgs a = {};
-      a.dtype = dt; a.split3 = split3;
+      a.dtype = dt; a.split3 = split3; a.x_image = s3img && !fold_qkv && !fold_gen;
       a.prenorm = fold_qkv; a.eps = d->eps;
       a.row_scale = fold_gen ? ws.rstd : nullptr;
       const void* w_plain = (dt == TTV_BF16 && lw.to_qkv_qs) ? lw.to_qkv_qs : lw.to_qkv;   // inference copy with scaled q rows, if packed
@@ -223,7 +227,8 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     else
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
-                               (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0), dt, s));
+                               (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
+                               (s3img ? TTV_ATTN_SPLIT_OUT : 0), dt, s));
     // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h).
     // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
     // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs
@@ -243,7 +248,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       continue;
     }
     GemmArgs o = {};
-    o.dtype = dt; o.split3 = split3;
+    o.dtype = dt; o.split3 = split3; o.x_image = s3img;
     o.x = ws.ao; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
     if (i == 0) {
       o.alpha = 1.f; o.y = ws.x; o.ldy = dm;
@@ -280,9 +285,9 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_gemm_fp8(EPI_GEGLU, f, f8_scales, lw.w12_f8_scale, s));
     } else {
     if (fold_ffd_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
-    if (!fold_ffd && !fold_ffd_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+    if (!fold_ffd && !fold_ffd_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s, nullptr, nullptr, nullptr, s3img));
     GemmArgs f = {};
-    f.dtype = dt; f.split3 = split3;
+    f.dtype = dt; f.split3 = split3; f.x_image = s3img && !fold_ffd && !fold_ffd_gen; f.y_image = s3img;
     f.prenorm = fold_ffd; f.eps = d->eps;
     f.row_scale = fold_ffd_gen ? ws.rstd : nullptr;
     f.x = (fold_ffd || fold_ffd_gen) ? ws.x : ws.xn; f.ldx = dm; f.w = (fold_ffd || fold_ffd_gen) ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
@@ -290,7 +295,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     }
     rstd_valid = false;
     GemmArgs f3 = {};
-    f3.dtype = dt; f3.split3 = split3;
+    f3.dtype = dt; f3.split3 = split3; f3.x_image = s3img;
     f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = L; f3.N = dm; f3.K = d->inner; f3.resid = ws.x; f3.ldr = dm;
     if (i == 0) {
       f3.alpha = 1.f; f3.y = ws.x; f3.ldy = dm;

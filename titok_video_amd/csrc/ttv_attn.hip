@@ -1297,7 +1297,8 @@ __device__ __forceinline__ void split4_f32(const uint4 v, uint2& hi, uint2& lo) 
 template <bool GATE>
 __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
                                                         const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
-                                                        int rep, float c_exp /* scale * log2(e) */) {
+                                                        int rep, float c_exp /* scale * log2(e) */, int out_image) {
+  // out_image: the output is written as out_proj's split image (hi0..3 | lo0..3 per four consecutive features) instead of fp32
   __shared__ __attribute__((aligned(16))) uint4 tiles[2][4][KB * 8];   // two stages of (K hi, K lo, V hi, V lo), 64 keys x 128 bytes each
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1498,7 +1499,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= 1.0f / (1.0f + expf(-gt[e]));
         }
-        *reinterpret_cast<f32x4*>(orow + d0) = v;
+        if (out_image) {
+          uint2 hi, lo;
+          split4_f32(__builtin_bit_cast(uint4, v), hi, lo);
+          *reinterpret_cast<uint4*>(orow + d0) = make_uint4(hi.x, hi.y, lo.x, lo.y);
+        } else {
+          *reinterpret_cast<f32x4*>(orow + d0) = v;
+        }
       }
   }
 }
@@ -1576,8 +1583,9 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
     const float c_exp = scale * 1.44269504088896340736f;
     if (flags & TTV_ATTN_SPLIT3) {
       TTV_CHECK_ARG(!lse_out, "attention: the split-bf16 kernel is an inference path (no tape outputs)");
-      if (gate_mul) hipLaunchKernelGGL((k_attn_split3<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
-      else hipLaunchKernelGGL((k_attn_split3<false>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp);
+      const int img = (flags & TTV_ATTN_SPLIT_OUT) ? 1 : 0;
+      if (gate_mul) hipLaunchKernelGGL((k_attn_split3<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
+      else hipLaunchKernelGGL((k_attn_split3<false>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
     } else if (gate_mul)
       hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);
     else

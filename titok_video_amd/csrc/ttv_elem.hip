@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int 
                                                  TO* __restrict__ out, int ld_out, const int* __restrict__ dst_rows,
                                                  const float* __restrict__ gain, int rows, int d, float eps,
                                                  float* __restrict__ next_rstd, uint8_t* __restrict__ mx_q = nullptr,
-                                                 uint8_t* __restrict__ mx_s = nullptr, int mx_ld = 0, int mx_nkp = 0) {
+                                                 uint8_t* __restrict__ mx_s = nullptr, int mx_ld = 0, int mx_nkp = 0, int split_image = 0) {
   // mx_q / mx_s (round 4, config #5): the row as STORED, additionally as block-scaled e4m3 (k_quant_mx_fp8's output for that row,
   // bit for bit) - the next linear's fp8 operand without a quantisation pass of its own.  Needs d % 128 == 0.
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -62,7 +62,15 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const TI* __restrict__ in, int 
     if (c < d) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
       f32x4 o = {v[it][0] * rstd * g[0], v[it][1] * rstd * g[1], v[it][2] * rstd * g[2], v[it][3] * rstd * g[3]};
-      Vec4<TO>::store(q + c, o);
+      if (sizeof(TO) == 4 && split_image) {      // split-bf16 towers: the row as the next linear's split image (same 16 bytes per four elements)
+        bf16x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hv[e] = (bf16_t)o[e]; lv[e] = (bf16_t)(o[e] - (float)hv[e]); }
+        const uint2 hp = __builtin_bit_cast(uint2, hv), lp = __builtin_bit_cast(uint2, lv);
+        *reinterpret_cast<uint4*>(q + c) = make_uint4(hp.x, hp.y, lp.x, lp.y);
+      } else {
+        Vec4<TO>::store(q + c, o);
+      }
       if (next_rstd) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float w = round_to<TO>(o[e]); so = fmaf(w, w, so); }
@@ -118,25 +126,26 @@ int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, i
 
 template <typename TI, typename TO>
 static int launch_rmsnorm(const void* in, int ld_in, const int* src_rows, void* out, int ld_out, const int* dst_rows,
-                          const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s) {
+                          const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s, int split_image) {
   if (rows == 0) return TTV_OK;
   TtvProfScope prof(TTV_KC_RMSNORM, s);
   const int nkp = (d / 128 + 3) / 4 * 4;
   hipLaunchKernelGGL((k_rmsnorm<TI, TO>), dim3(ttv_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, s, (const TI*)in, ld_in,
-                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps, next_rstd, (uint8_t*)mx_q, (uint8_t*)mx_s, 4 * nkp, nkp);
+                     src_rows, (TO*)out, ld_out, dst_rows, gain, rows, d, eps, next_rstd, (uint8_t*)mx_q, (uint8_t*)mx_s, 4 * nkp, nkp, split_image);
   TTV_CHECK_LAUNCH("rmsnorm");
   return TTV_OK;
 }
 
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
-                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s) {
+                 const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s,
+                 int split_image) {
   TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS, "rmsnorm: width %d must be a multiple of 4 and <= 1024", d);
   TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "rmsnorm: leading dims must be multiples of 4");
   TTV_CHECK_ARG(!mx_q || (mx_s && d % 128 == 0 && (uintptr_t)mx_q % 4 == 0), "rmsnorm: the block-scaled fp8 side output needs its scale buffer and width %% 128 == 0");
-  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
-  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
-  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
-  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s);
+  if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
+  if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
+  if (in_dtype == TTV_BF16 && out_dtype == TTV_F32) return launch_rmsnorm<bf16_t, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
   ttv_set_error("rmsnorm: bad dtypes %d %d", in_dtype, out_dtype);
   return TTV_ERR_INVALID;
 }

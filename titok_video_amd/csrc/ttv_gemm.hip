@@ -47,6 +47,7 @@ struct GemmDev {
   float* sum_f32; int ld_sum;                   // optional [M, N] fp32: alpha * resid + acc (what the post-norm's backward needs)
   void* y2; int ldy2; const float* norm_gain2;  // optional [M, N] dtype: RMSNorm(y) * norm_gain2 with y as stored (rounded): the next pre-norm's output
   int split3;                                   // fp32 kernel: w is the split-bf16 image (hi | lo per 16-byte chunk), products in three bf16 passes
+  int x_image, y_image;                         // split3: x already IS a split image (its producer wrote it) / the fp32 output is written as one
   const uint8_t* x_mx; const uint8_t* w_mx;     // MX block scales (E8M0, k_quant_mx_fp8's layout), ld_mx bytes per row
   int ld_mx;
   uint8_t* yq; uint8_t* yq_mx; int ld_yq_mx, yq_nkp;   // EPI_GEGLU of the MX kernel: h leaves as block-scaled e4m3 [M, N] + scales instead of bf16
@@ -76,6 +77,16 @@ __device__ __forceinline__ float gelu_erf_as(float v) {
 __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
   bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
   return __builtin_bit_cast(uint2, b);
+}
+
+// split image of four fp32 values (one 16-byte chunk): (hi0..3 | lo0..3), hi = bf16(x) (round to nearest even), lo = bf16(x - hi)
+__device__ __forceinline__ uint4 split4_bf16(uint4 v) {
+  const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+  const bf16_t h0 = (bf16_t)x0, h1 = (bf16_t)x1, h2 = (bf16_t)x2, h3 = (bf16_t)x3;       // round to nearest even (v_cvt_pk_bf16_f32)
+  const bf16_t l0 = (bf16_t)(x0 - (float)h0), l1 = (bf16_t)(x1 - (float)h1), l2 = (bf16_t)(x2 - (float)h2), l3 = (bf16_t)(x3 - (float)h3);
+  const bf16x4 hv = {h0, h1, h2, h3}, lv = {l0, l1, l2, l3};
+  const uint2 hp = __builtin_bit_cast(uint2, hv), lp = __builtin_bit_cast(uint2, lv);
+  return make_uint4(hp.x, hp.y, lp.x, lp.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,6 +244,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
         }
       }
     }
+  } else if (sizeof(T) == 4 && p.y_image) {
+    // split-bf16 towers: a lane's four consecutive features are one 16-byte chunk of the NEXT linear's split image (hi0..3 | lo0..3)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (tv[j] && fv[i])
+          *reinterpret_cast<uint4*>((float*)p.y + (size_t)tok[j] * p.ldy + feat[i]) = split4_bf16(__builtin_bit_cast(uint4, acc[i][j]));
   } else {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -1677,14 +1696,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
 // very same copies; the token operand is split by the staging threads between the global load and the LDS store (once per element and
 // block).  A lane's chunks kq and kq + 4 of the 32-wide k-tile are the two halves of its 8-element bf16 fragment (hi: dwords x, y of
 // both chunks, lo: z, w) - the same k assignment for both operands, so v_mfma_f32_16x16x32_bf16 pairs equal k.
-__device__ __forceinline__ uint4 split4_bf16(uint4 v) {
-  const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
-  const bf16_t h0 = (bf16_t)x0, h1 = (bf16_t)x1, h2 = (bf16_t)x2, h3 = (bf16_t)x3;       // round to nearest even (v_cvt_pk_bf16_f32)
-  const bf16_t l0 = (bf16_t)(x0 - (float)h0), l1 = (bf16_t)(x1 - (float)h1), l2 = (bf16_t)(x2 - (float)h2), l3 = (bf16_t)(x3 - (float)h3);
-  const bf16x4 hv = {h0, h1, h2, h3}, lv = {l0, l1, l2, l3};
-  const uint2 hp = __builtin_bit_cast(uint2, hv), lp = __builtin_bit_cast(uint2, lv);
-  return make_uint4(hp.x, hp.y, lp.x, lp.y);
-}
 
 template <int EPI, bool SPLIT = false, int NJ = 4>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
@@ -1746,7 +1757,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
     sx3 = ok__ ? *reinterpret_cast<const uint4*>(X + xo3 + (k0)) : zero4;           \
     if (NJ == 5) sx4 = ok__ ? *reinterpret_cast<const uint4*>(X + xo4 + (k0)) : zero4; \
   } while (0)
-#define FSPLIT(v_) (SPLIT ? split4_bf16(v_) : (v_))
+#define FSPLIT(v_) ((SPLIT && !p.x_image) ? split4_bf16(v_) : (v_))
 #define FLSTORE(buf)                                                                \
   do {                                                                              \
     lds[buf][li0] = sw0; lds[buf][li0 + 32 * 8] = sw1; lds[buf][li0 + 64 * 8] = sw2; lds[buf][li0 + 96 * 8] = sw3;            \
@@ -1996,6 +2007,8 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.debug = g_ttv_debug;
   d.sum_f32 = a.sum_f32; d.ld_sum = a.ld_sum; d.y2 = a.y2; d.ldy2 = a.ldy2; d.norm_gain2 = a.norm_gain2;
   d.split3 = (a.split3 && a.dtype == TTV_F32) ? 1 : 0;
+  d.x_image = d.split3 && a.x_image; d.y_image = d.split3 && a.y_image;
+  TTV_CHECK_ARG(!d.y_image || epi == EPI_STORE || epi == EPI_GEGLU, "gemm: a split-image output is a STORE / GEGLU option");
   d.x_mx = d.w_mx = nullptr; d.ld_mx = 0;
   d.norm_gain = a.norm_gain;
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;

@@ -8,7 +8,8 @@
 // ---- ttv_elem.hip ----
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
                  const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd = nullptr,
-                 void* mx_q = nullptr, void* mx_s = nullptr);   // mx_q / mx_s: the stored row also as block-scaled e4m3 [rows, d] + its E8M0 scales
+                 void* mx_q = nullptr, void* mx_s = nullptr,    // mx_q / mx_s: the stored row also as block-scaled e4m3 [rows, d] + its E8M0 scales
+                 int split_image = 0);                          // fp32 output written as the split-bf16 image (hi0..3 | lo0..3 per four elements)
 int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, int d, float eps, hipStream_t s);
 int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* mask_token,
                          const float* gain, float eps, hipStream_t s);
@@ -69,6 +70,7 @@ struct GemmArgs {
                                    // (k_quant_mx_fp8's layout for width N) instead of bf16 y - the next linear's operand, no pass of its own
   int split3;                      // fp32 only: w is the split-bf16 image of the weight (ttv_split3_pack) and the products run as three bf16
                                    // MFMA passes (k_gemm_f32<.., SPLIT>)
+  int x_image, y_image;            // split3: x is already a split image (written by its producer: no split in the staging) / y is written as one
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
   const float* row_scale;          // optional [M]: output row t is multiplied by row_scale[t] before the epilogue (the rstd of a pre-norm
                                    // whose gain is folded into w: any K; bf16 kernels)
