@@ -178,7 +178,8 @@ def test_split3_encoder_mixed_shapes_against_the_oracle():
 def test_split_images_written_by_the_producers_change_no_bit():
     """The split towers' norm kernels, attention epilogue and GEGLU epilogue write the next linear's operand as its split image (same bytes
     as the fp32 tensor); with ttv_debug_set bit 12 the activations stay fp32 and the GEMM's staging threads split them.  Same values,
-    same split: the encoder's tokens must be equal bit for bit."""
+    same split: the encoder's tokens must be equal bit for bit - also between the LDS-DMA split GEMM (k_gemm_split_dma, both operands images)
+    and the register-staged one (bit 13)."""
     levels = [7, 5, 5, 5, 5]
     sd = seeded_titok_state(0)
     shapes, counts = [(8, 32, 48), (4, 16, 16), (16, 64, 64)], [17, 1, 128]
@@ -187,7 +188,7 @@ def test_split_images_written_by_the_producers_change_no_bit():
     model.load_state_dict(sd, strict=True)
     model = model.to(DEV, torch.float32).eval().set_index_exact("split3")
     outs = []
-    for bit in (0, 4096):
+    for bit in (0, 8192, 4096):      # default (images + LDS-DMA GEMM) | images, register-staged GEMM | fp32 activations, split in the GEMM
         L().ttv_debug_set(bit)
         try:
             with torch.no_grad():
@@ -196,4 +197,4 @@ def test_split_images_written_by_the_producers_change_no_bit():
         finally:
             L().ttv_debug_set(0)
         outs.append(z)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -1854,6 +1854,134 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 linear with BOTH operands staged by LDS-DMA (round 4): when the token operand already is a split image (its producer wrote
+// it: GemmArgs.x_image) the k-tile of 32 k values is 128 bytes per row for both operands - byte for byte the stage image, swizzle and
+// LDS-DMA staging of k_gemm_fp8_dma / k_gemm_bf16_dma: no staging registers, no ds_write, nothing to convert.  Fragments and the three
+// MFMA passes as in k_gemm_f32<.., SPLIT>; fp32 epilogues.  K % 32 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int NJ>
+__global__ __launch_bounds__(256, 2) void k_gemm_split_dma(GemmDev p, int n_ftiles) {
+  constexpr bool DUAL = (EPI == EPI_GEGLU);
+  constexpr int FT = DUAL ? 64 : TF;
+  constexpr int TTK = 32 * NJ;
+  constexpr int XI = TTK / 32;
+  __shared__ __attribute__((aligned(16))) uint4 lds[2][(TF + TTK) * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = wave & 1, wt = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int fbase = (tile % n_ftiles) * FT;
+  const int tbase = (tile / n_ftiles) * TTK;
+  const char* W = (const char*)p.w;
+  const char* X = (const char*)p.x;
+
+  const int lr = lane >> 3, lp = lane & 7;
+  uint32_t woff[4], xoff[XI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lr;
+    int wr;
+    if (DUAL) wr = row < 64 ? fbase + row : p.N + fbase + (row - 64);
+    else wr = fbase + row;
+    wr = wr < p.w_rows ? wr : p.w_rows - 1;
+    woff[i] = ((uint32_t)wr * (uint32_t)p.ldw) * 4u + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = wave * (8 * XI) + i * 8 + lr;
+    int xr = tbase + row;
+    xr = xr < p.M ? xr : p.M - 1;
+    xoff[i] = ((uint32_t)xr * (uint32_t)p.ldx) * 4u + (uint32_t)((lp ^ ((row >> 1) & 7)) * 16);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&lds[0][0];
+  constexpr uint32_t BUFB = (TF + TTK) * 128;
+#define GS_DMA(voff_, base_, dst_)                                                                               \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                 \
+  } while (0)
+#define GS_STAGE(kt_, buf_)                                                                                      \
+  do {                                                                                                           \
+    const char* wb__ = W + (size_t)(kt_) * 128;                                                                  \
+    const char* xb__ = X + (size_t)(kt_) * 128;                                                                  \
+    const uint32_t dw__ = lds0 + (buf_) * BUFB + wave * 4096;                                                    \
+    const uint32_t dx__ = lds0 + (buf_) * BUFB + TF * 128 + wave * (1024 * XI);                                  \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) GS_DMA(woff[i__], wb__, dw__ + i__ * 1024);              \
+    _Pragma("unroll") for (int i__ = 0; i__ < XI; ++i__) GS_DMA(xoff[i__], xb__, dx__ + i__ * 1024);             \
+  } while (0)
+
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nk = p.K / 32;
+  GS_STAGE(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) GS_STAGE(kt + 1, buf ^ 1);
+    bf16x8 ah[4], al[4], bh[NJ], bl[NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+      const int sw = (arow >> 1) & 7;
+      const uint4 c0 = lds[buf][arow * 8 + (kq ^ sw)], c1 = lds[buf][arow * 8 + ((kq + 4) ^ sw)];
+      ah[i] = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+      al[i] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.z, c1.w));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int brow = wt * (16 * NJ) + j * 16 + l15;
+      const int sw = (brow >> 1) & 7;
+      const uint4 c0 = lds[buf][TF * 8 + brow * 8 + (kq ^ sw)], c1 = lds[buf][TF * 8 + brow * 8 + ((kq + 4) ^ sw)];
+      bh[j] = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+      bl[j] = __builtin_bit_cast(bf16x8, make_uint4(c0.z, c0.w, c1.z, c1.w));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+#undef GS_STAGE
+#undef GS_DMA
+
+  int tok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) tok[j] = tbase + wt * (16 * NJ) + j * 16 + l15;
+  if (DUAL) {
+    int feat[2];
+    f32x4 ax[2][NJ], ag[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      feat[i] = fbase + wf * 32 + i * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { ax[i][j] = acc[i][j]; ag[i][j] = acc[i + 2][j]; }
+    }
+    epilogue_tile<EPI, float, 2, NJ>(p, tok, feat, ax, ag, kq);
+  } else {
+    int feat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) feat[i] = fbase + wf * 64 + i * 16 + kq * 4;
+    epilogue_tile<EPI, float, 4, NJ>(p, tok, feat, acc, acc, kq);
+  }
+}
+
 template <int EPI>
 static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
   if (dtype == TTV_BF16 && d.K == 256 && d.N % 8 == 0) {
@@ -1926,7 +2054,15 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     const int nf = ttv_cdiv(d.N, (EPI == EPI_GEGLU) ? 64 : F_TF), nt = ttv_cdiv(d.M, F_TT), nt160 = ttv_cdiv(d.M, 160);
     const long c128 = (long)ttv_cdiv(nf * nt, 512) * 128, c160 = (long)ttv_cdiv(nf * nt160, 512) * 160;
     const bool t160 = ((c160 < c128) && !(d.debug & 256)) || (d.debug & 128);
-    if (d.split3) {
+    // split image on both sides and whole 32-wide k-tiles: both operands by LDS-DMA (TTV_SPLIT3_DMA=0 / ttv_debug_set bit 13: the
+    // register-staged kernel, A/B and tests); byte offsets must fit 32 bits
+    static const bool s3dma_env = !(getenv("TTV_SPLIT3_DMA") && getenv("TTV_SPLIT3_DMA")[0] == '0');
+    const bool s3dma = d.split3 && d.x_image && s3dma_env && !(d.debug & 8192) && d.K % 32 == 0 && d.ldx % 4 == 0 && d.ldw % 4 == 0 &&
+                       (uint64_t)d.M * (uint64_t)d.ldx * 4u < (1ull << 32) && (uint64_t)d.w_rows * (uint64_t)d.ldw * 4u < (1ull << 32);
+    if (s3dma) {
+      if (t160) hipLaunchKernelGGL((k_gemm_split_dma<EPI, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+      else hipLaunchKernelGGL((k_gemm_split_dma<EPI, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    } else if (d.split3) {
       if (t160) hipLaunchKernelGGL((k_gemm_f32<EPI, true, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
       else hipLaunchKernelGGL((k_gemm_f32<EPI, true, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
     } else {
