@@ -689,3 +689,25 @@ def test_clip_from_u8_equals_the_host_normalisation(dt, shape):
     out = torch.empty((3, t, h, w), dtype=DT[dt], device=DEV)
     _lib.check(L().ttv_clip_from_u8(d8.data_ptr(), t, h, w, out.data_ptr(), _lib.dtype_code(DT[dt]), S()), "clip_from_u8")
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(300, 256, 768), (1000, 1408, 256), (129, 768, 704), (36864, 256, 256)])
+def test_linear_f32_lds_dma_staging_is_bit_identical(shape):
+    """Round 4: the exact-fp32 GEMM stages both operands by LDS-DMA when K is a multiple of 32 (k_gemm_split_dma<.., false>); ttv_debug_set
+    bit 13 selects the register-staged kernel.  Same products, same summation order: equal bit for bit (and against float64 as usual)."""
+    M, N, K = shape
+    x, w, g = _lin_inputs(M, N, K, "f32", M + K)
+    b = (torch.randn(N, generator=g) * 0.1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    outs = []
+    for bit in (0, 8192):
+        y = torch.full((M, N), float("nan"), device=DEV)
+        L().ttv_debug_set(bit)
+        try:
+            _lib.check(L().ttv_linear(xd.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), None, y.data_ptr(), N, M, N, K, _lib.TTV_F32, S()), "linear")
+            torch.cuda.synchronize()
+        finally:
+            L().ttv_debug_set(0)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert_close(outs[0], x.double() @ w.double().T + b.double(), "f32")

@@ -1860,7 +1860,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmDev p, int n_ftiles) {
 // LDS-DMA staging of k_gemm_fp8_dma / k_gemm_bf16_dma: no staging registers, no ds_write, nothing to convert.  Fragments and the three
 // MFMA passes as in k_gemm_f32<.., SPLIT>; fp32 epilogues.  K % 32 == 0.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int NJ>
+template <int EPI, int NJ, bool SPLIT = true>
 __global__ __launch_bounds__(256, 2) void k_gemm_split_dma(GemmDev p, int n_ftiles) {
   constexpr bool DUAL = (EPI == EPI_GEGLU);
   constexpr int FT = DUAL ? 64 : TF;
@@ -1926,6 +1926,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split_dma(GemmDev p, int n_ftil
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) GS_STAGE(kt + 1, buf ^ 1);
+    if constexpr (SPLIT) {
     bf16x8 ah[4], al[4], bh[NJ], bl[NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1955,6 +1956,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split_dma(GemmDev p, int n_ftil
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    } else {
+      // exact fp32 (SPLIT = false): the same stage image holds plain fp32 rows; products and summation order of k_gemm_f32 (a lane's
+      // chunk kc = 4 kb + kq holds k = 4 kc .. 4 kc + 3, MFMA step jj of a 16-k block sums k in {jj, 4 + jj, 8 + jj, 12 + jj})
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x4 a[4], b[NJ];
+        const int kc = kb * 4 + kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int arow = (DUAL ? (i < 2 ? wf * 32 + i * 16 : 64 + wf * 32 + (i - 2) * 16) : wf * 64 + i * 16) + l15;
+          a[i] = __builtin_bit_cast(f32x4, lds[buf][arow * 8 + (kc ^ ((arow >> 1) & 7))]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int brow = wt * (16 * NJ) + j * 16 + l15;
+          b[j] = __builtin_bit_cast(f32x4, lds[buf][TF * 8 + brow * 8 + (kc ^ ((brow >> 1) & 7))]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][jj], b[j][jj], acc[i][j], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
@@ -2065,6 +2091,11 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     } else if (d.split3) {
       if (t160) hipLaunchKernelGGL((k_gemm_f32<EPI, true, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
       else hipLaunchKernelGGL((k_gemm_f32<EPI, true, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
+    } else if (s3dma_env && !(d.debug & 8192) && d.K % 32 == 0 && d.ldx % 4 == 0 && d.ldw % 4 == 0 &&
+               (uint64_t)d.M * (uint64_t)d.ldx * 4u < (1ull << 32) && (uint64_t)d.w_rows * (uint64_t)d.ldw * 4u < (1ull << 32)) {
+      // exact fp32 with both operands by LDS-DMA: the same products in the same order as the register-staged kernel (bit-identical)
+      if (t160) hipLaunchKernelGGL((k_gemm_split_dma<EPI, 5, false>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
+      else hipLaunchKernelGGL((k_gemm_split_dma<EPI, 4, false>), dim3(nf * nt), dim3(256), 0, s, d, nf);
     } else {
       if (t160) hipLaunchKernelGGL((k_gemm_f32<EPI, false, 5>), dim3(nf * nt160), dim3(256), 0, s, d, nf);
       else hipLaunchKernelGGL((k_gemm_f32<EPI, false, 4>), dim3(nf * nt), dim3(256), 0, s, d, nf);
