@@ -211,6 +211,8 @@ int ttv_decoder_embed(const void* codes, int token_size, const void* w, const vo
                                 softmax and accumulation (~2^-17 relative per product); the towers set it with ttv_tower_weights.f32_split3 */
 #define TTV_ATTN_SPLIT_OUT 64 /* with TTV_ATTN_SPLIT3: the output is written as the split image of the following linear's operand (ttv_split3_pack's
                                 format, same bytes as the fp32 output) */
+#define TTV_ATTN_SPLIT_IN 128 /* with TTV_ATTN_SPLIT3: q, k and v arrive as planar split images (per 8 features hi0..7 | lo0..7, what the to_qkv linear
+                                 of a split tower writes; the gate columns fp32): staged by LDS-DMA */
 int ttv_attention(const void* qkvg, int ld, void* out, int ldo, const int32_t* cu_seqlens, const int32_t* qblocks,
                   int n_qblocks, int q_heads, int kv_heads, int head_dim, int flags, int dtype, void* stream);
 /* The same operator (transformer.py:100,103) on the 64-query-rows-per-wave kernel: bf16, head_dim 64, q pre-scaled (flags must carry

@@ -208,7 +208,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       // staging threads copy bytes); TTV_SPLIT3_IMAGES=0 keeps fp32 activations and the split in the GEMM (A/B)
       if (!fold_qkv && !fold_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.pre_ln, L, dm, d->eps, s, nullptr, nullptr, nullptr, s3img));
       GemmArgs a = {};
-      a.dtype = dt; a.split3 = split3; a.x_image = s3img && !fold_qkv && !fold_gen;
+      a.dtype = dt; a.split3 = split3; a.x_image = s3img && !fold_qkv && !fold_gen; a.y_image = s3img ? 2 : 0;
       a.prenorm = fold_qkv; a.eps = d->eps;
       a.row_scale = fold_gen ? ws.rstd : nullptr;
       const void* w_plain = (dt == TTV_BF16 && lw.to_qkv_qs) ? lw.to_qkv_qs : lw.to_qkv;   // inference copy with scaled q rows, if packed
@@ -228,7 +228,7 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
                                (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
-                               (s3img ? TTV_ATTN_SPLIT_OUT : 0), dt, s));
+                               (s3img ? (TTV_ATTN_SPLIT_OUT | TTV_ATTN_SPLIT_IN) : 0), dt, s));
     // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h).
     // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
     // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs

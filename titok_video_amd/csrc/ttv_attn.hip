@@ -1294,7 +1294,10 @@ __device__ __forceinline__ void split4_f32(const uint4 v, uint2& hi, uint2& lo) 
   lo = __builtin_bit_cast(uint2, lv);
 }
 
-template <bool GATE>
+// IMG (round 4): q, k and v arrive as the to_qkv epilogue's planar images (per 8 features hi0..7 | lo0..7; GemmArgs.y_image = 2): the Q
+// fragments are two 16-byte loads each, and the four bf16 tiles of a stage are filled by LDS-DMA (a 16-byte chunk of a tile row IS a
+// 16-byte chunk of the image; swizzle on the source side) - no staging registers, no ds_write, no split arithmetic for K and V.
+template <bool GATE, bool IMG = false>
 __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict__ qkvg, int ld, float* __restrict__ out, int ldo,
                                                         const int* __restrict__ cu, const int* __restrict__ qblocks, int d_model, int gqa,
                                                         int rep, float c_exp /* scale * log2(e) */, int out_image) {
@@ -1323,11 +1326,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
   for (int ks = 0; ks < 4; ++ks) {
     const uint4 a = *reinterpret_cast<const uint4*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8);
     const uint4 b = *reinterpret_cast<const uint4*>(qbase + (size_t)qrc * ld + ks * 16 + h * 8 + 4);
-    uint2 ah, al, bh, bl;
-    split4_f32(a, ah, al);
-    split4_f32(b, bh, bl);
-    qh[ks] = __builtin_bit_cast(bf16x8, make_uint4(ah.x, ah.y, bh.x, bh.y));
-    ql[ks] = __builtin_bit_cast(bf16x8, make_uint4(al.x, al.y, bl.x, bl.y));
+    if (IMG) {                    // the group of 8 features IS (hi0..7 | lo0..7)
+      qh[ks] = __builtin_bit_cast(bf16x8, a);
+      ql[ks] = __builtin_bit_cast(bf16x8, b);
+    } else {
+      uint2 ah, al, bh, bl;
+      split4_f32(a, ah, al);
+      split4_f32(b, bh, bl);
+      qh[ks] = __builtin_bit_cast(bf16x8, make_uint4(ah.x, ah.y, bh.x, bh.y));
+      ql[ks] = __builtin_bit_cast(bf16x8, make_uint4(al.x, al.y, bl.x, bl.y));
+    }
   }
 
   // staging: a tile is 64 keys x 16 float chunks; thread t takes float chunk t & 15 (dims 4 sch .. 4 sch + 3) of keys (t >> 4) + 16 i
@@ -1382,14 +1390,49 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
+  // IMG: LDS-DMA staging.  Plane pl (K hi, K lo, V hi, V lo) of a stage is 64 rows x 8 chunks; one instruction fills 8 rows (lane >> 3 =
+  // row, lane & 7 = chunk position), wave w rows 16 w .. 16 w + 15 of every plane: 8 instructions per wave and tile.  Position p of a K
+  // row holds logical chunk p ^ ((row >> 1) & 7), of a V row p ^ (((row >> 1) & 1) << 2); logical chunk c of plane hi / lo is image bytes
+  // 32 c / 32 c + 16 of the row's 64 features.
+  const uint32_t tiles_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&tiles[0][0][0];
+  const int drow = lane >> 3, dpos = lane & 7;
+#define S3_DMA(voff_, base_, dst_)                                                                               \
+  do {                                                                                                           \
+    unsigned keep__;                                                                                             \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                 \
+  } while (0)
+#define S3_DMA_TILE(kt_, stage_)                                                                                 \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 2; ++i__) {                                                        \
+      const int row__ = wave * 16 + i__ * 8 + drow;                                                              \
+      int key__ = (kt_) * KB + row__;                                                                            \
+      key__ = key__ < S ? key__ : S - 1;                                                                         \
+      const uint32_t rb__ = (uint32_t)key__ * (uint32_t)ld * 4u;                                                 \
+      const uint32_t kc__ = (uint32_t)((dpos ^ ((row__ >> 1) & 7)) * 32);                                        \
+      const uint32_t vc__ = (uint32_t)((dpos ^ (((row__ >> 1) & 1) << 2)) * 32);                                 \
+      const uint32_t dst__ = tiles_lds + (stage_) * STAGE + (wave * 16 + i__ * 8) * 128;                         \
+      S3_DMA(rb__ + kc__, kbase, dst__);                                                                         \
+      S3_DMA(rb__ + kc__ + 16u, kbase, dst__ + PLANE);                                                           \
+      S3_DMA(rb__ + vc__, vbase, dst__ + 2 * PLANE);                                                             \
+      S3_DMA(rb__ + vc__ + 16u, vbase, dst__ + 3 * PLANE);                                                       \
+    }                                                                                                            \
+  } while (0)
   // two LDS stages, one barrier per tile: while a wave computes on stage kt & 1 it has already written tile kt + 1 into the other stage
   // (from the registers loaded one tile earlier) and has tile kt + 2's global loads in flight
-  S3_GLOAD(0);
-  S3_LSTORE(0);
-  if (nkt > 1) S3_GLOAD(1);
+  if (IMG) {
+    S3_DMA_TILE(0, 0);
+  } else {
+    S3_GLOAD(0);
+    S3_LSTORE(0);
+    if (nkt > 1) S3_GLOAD(1);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
+    if (IMG) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile kt has landed
     __syncthreads();            // stage kt & 1 is complete; every wave is done computing on the other stage
-    if (kt + 1 < nkt) {
+    if (IMG) {
+      if (kt + 1 < nkt) S3_DMA_TILE(kt + 1, (kt + 1) & 1);
+    } else if (kt + 1 < nkt) {
       S3_LSTORE((kt + 1) & 1);
       if (kt + 2 < nkt) S3_GLOAD(kt + 2);
     }
@@ -1480,6 +1523,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_split3(const float* __restrict_
   }
 #undef S3_GLOAD
 #undef S3_LSTORE
+#undef S3_DMA_TILE
+#undef S3_DMA
   if (!wave_live) return;
 
   // ---- normalise, gate, store (fp32, exact division and sigmoid as k_attn_f32): lane holds O[query r][32 dt + 8 g + 4 h + 0..3] ----
@@ -1584,7 +1629,10 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
     if (flags & TTV_ATTN_SPLIT3) {
       TTV_CHECK_ARG(!lse_out, "attention: the split-bf16 kernel is an inference path (no tape outputs)");
       const int img = (flags & TTV_ATTN_SPLIT_OUT) ? 1 : 0;
-      if (gate_mul) hipLaunchKernelGGL((k_attn_split3<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
+      if (flags & TTV_ATTN_SPLIT_IN) {
+        if (gate_mul) hipLaunchKernelGGL((k_attn_split3<true, true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
+        else hipLaunchKernelGGL((k_attn_split3<false, true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
+      } else if (gate_mul) hipLaunchKernelGGL((k_attn_split3<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
       else hipLaunchKernelGGL((k_attn_split3<false>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, img);
     } else if (gate_mul)
       hipLaunchKernelGGL((k_attn_f32<true>), grid, dim3(256), 0, s, (const float*)qkvg, ld, (float*)out, ldo, cu_seqlens, qblocks, d_model, gqa, rep, c_exp, lse_out);

@@ -244,6 +244,26 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
         }
       }
     }
+  } else if (sizeof(T) == 4 && p.y_image == 2) {
+    // split-bf16 towers, to_qkv: q, k and v leave as the ATTENTION kernel's operand format - per aligned group of 8 features the 32 bytes
+    // (hi0..7 | lo0..7), so that a 16-byte chunk is 8 consecutive hi (or lo) values: what its LDS-DMA copies and its fragment loads take as
+    // they are.  A lane's 4 features are half a group: 8 bytes of hi, 8 bytes of lo.  The gate columns (between the rotary ranges) stay fp32.
+    const int f_first = __builtin_amdgcn_readfirstlane(feat[0]);
+    const bool plain = f_first >= p.rope_q_end && f_first < p.rope_k_begin;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (tv[j] && fv[i]) {
+          if (plain) {
+            *reinterpret_cast<f32x4*>((float*)p.y + (size_t)tok[j] * p.ldy + feat[i]) = acc[i][j];
+          } else {
+            const uint4 im = split4_bf16(__builtin_bit_cast(uint4, acc[i][j]));
+            char* g8 = reinterpret_cast<char*>((float*)p.y + (size_t)tok[j] * p.ldy + (feat[i] & ~7)) + ((feat[i] >> 2) & 1) * 8;
+            *reinterpret_cast<uint2*>(g8) = make_uint2(im.x, im.y);
+            *reinterpret_cast<uint2*>(g8 + 16) = make_uint2(im.z, im.w);
+          }
+        }
   } else if (sizeof(T) == 4 && p.y_image) {
     // split-bf16 towers: a lane's four consecutive features are one 16-byte chunk of the NEXT linear's split image (hi0..3 | lo0..3)
 #pragma unroll
@@ -2174,8 +2194,9 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.debug = g_ttv_debug;
   d.sum_f32 = a.sum_f32; d.ld_sum = a.ld_sum; d.y2 = a.y2; d.ldy2 = a.ldy2; d.norm_gain2 = a.norm_gain2;
   d.split3 = (a.split3 && a.dtype == TTV_F32) ? 1 : 0;
-  d.x_image = d.split3 && a.x_image; d.y_image = d.split3 && a.y_image;
-  TTV_CHECK_ARG(!d.y_image || epi == EPI_STORE || epi == EPI_GEGLU, "gemm: a split-image output is a STORE / GEGLU option");
+  d.x_image = d.split3 && a.x_image; d.y_image = d.split3 ? a.y_image : 0;
+  TTV_CHECK_ARG(!d.y_image || (d.y_image == 1 && (epi == EPI_STORE || epi == EPI_GEGLU)) || (d.y_image == 2 && epi == EPI_QKV_ROPE),
+                "gemm: a split-image output is a STORE / GEGLU option (y_image 1) or the to_qkv layout (y_image 2)");
   d.x_mx = d.w_mx = nullptr; d.ld_mx = 0;
   d.norm_gain = a.norm_gain;
   d.clip_desc = a.clip_desc; d.patch_rows = a.patch_rows; d.row_seq = a.row_seq; d.clip0 = 0; d.pt_shift = d.ph_shift = 0;

@@ -71,6 +71,8 @@ struct GemmArgs {
   int split3;                      // fp32 only: w is the split-bf16 image of the weight (ttv_split3_pack) and the products run as three bf16
                                    // MFMA passes (k_gemm_f32<.., SPLIT>)
   int x_image, y_image;            // split3: x is already a split image (written by its producer: no split in the staging) / y is written as one
+                                   // (1: per four features hi0..3 | lo0..3, STORE / GEGLU; 2: to_qkv - q, k, v per eight features hi0..7 | lo0..7,
+                                   // the attention kernel's operand format, gate columns fp32)
   int prenorm;                     // 1: w has the RMSNorm gain folded in, x is the un-normalised row (bf16, K == 256 only)
   const float* row_scale;          // optional [M]: output row t is multiplied by row_scale[t] before the epilogue (the rstd of a pre-norm
                                    // whose gain is folded into w: any K; bf16 kernels)
