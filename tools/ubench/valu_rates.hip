@@ -9,6 +9,7 @@
 // makespan / (iters x w x per_iter) = cycles per instruction (or per iteration) PER SIMD, next to mean(t1 - t0) / (iters x per_iter),
 // what one wave waits for its own instruction.  Check: "mfma alone" must read ~32 per SIMD at every occupancy.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <cstdio>
 #include <algorithm>
 #include <vector>
@@ -91,6 +92,67 @@ __global__ void k(float* out, long long* cyc, int iters) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (KIND >= 40 && KIND < 43) {
+    // round 4: the same FLOPs on v_mfma_f32_16x16x32_bf16 (two of them per 32x32x16: 32 per iteration), same vector work:
+    // 40 = the MFMAs alone, 41 = phases (32 mfma16 | 96 plain + 32 exp2), 42 = interleaved 16 x (2 mfma16, 2 exp2, 6 plain).
+    // Does the smaller shape's longer hold on the issue port (8 of 16 cycles instead of 8 of 32) cost a loop with this much vector work?
+    typedef __attribute__((ext_vector_type(4))) float f32x4_;
+    f32x4_ c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
+    bf16x8 a2 = a, b2 = b;
+    for (int i = 0; i < 8; ++i) { a2[i] = (__bf16)(threadIdx.x * 0.02f + i); b2[i] = (__bf16)(i * 0.3f - 1.f); }
+    asm volatile("" : "+v"(a2), "+v"(b2));
+    for (int it = 0; it < iters; ++it) {
+      if (KIND == 40 || KIND == 41) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c3, 0, 0, 0);
+          c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c4, 0, 0, 0); c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, c5, 0, 0, 0);
+          c6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, c6, 0, 0, 0); c7 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c7, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (KIND == 41) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              v[i] = __builtin_amdgcn_exp2f(v[i]);
+              w[i] = w[i] + 1.25f;
+              w[(i + 5) & 15] = w[(i + 5) & 15] * 0.75f;
+              w[(i + 9) & 15] = w[(i + 9) & 15] + 0.5f;
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i & 1) { c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0); }
+          else { c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0); }
+          v[i] = __builtin_amdgcn_exp2f(v[i]);
+          v[(i + 8) & 15] = __builtin_amdgcn_exp2f(v[(i + 8) & 15]);
+          w[i] = w[i] + 1.25f; w[(i + 3) & 15] = w[(i + 3) & 15] * 0.75f; w[(i + 5) & 15] = w[(i + 5) & 15] + 0.5f;
+          w[(i + 7) & 15] = w[(i + 7) & 15] * 1.5f; w[(i + 9) & 15] = w[(i + 9) & 15] + 0.25f; w[(i + 11) & 15] = w[(i + 11) & 15] * 0.5f;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    for (int e = 0; e < 4; ++e) acc[e] += c0[e] + c1[e] + c2[e] + c3[e] + c4[e] + c5[e] + c6[e] + c7[e];
+  }
+  if (KIND == 43) {
+    // the 32x32x16 counterpart of 42: 16 x (1 mfma32, 2 exp2, 6 plain)
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        v[i] = __builtin_amdgcn_exp2f(v[i]);
+        v[(i + 8) & 15] = __builtin_amdgcn_exp2f(v[(i + 8) & 15]);
+        w[i] = w[i] + 1.25f; w[(i + 3) & 15] = w[(i + 3) & 15] * 0.75f; w[(i + 5) & 15] = w[(i + 5) & 15] + 0.5f;
+        w[(i + 7) & 15] = w[(i + 7) & 15] * 1.5f; w[(i + 9) & 15] = w[(i + 9) & 15] + 0.25f; w[(i + 11) & 15] = w[(i + 11) & 15] * 0.5f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
   if (KIND >= 20 && KIND < 30) {
     // the non-ALU ingredients of an attention tile, per iteration: 20 = 8 ds_read_b128 + 16 ds_read_b64 (consumed by a cheap xor),
     // 21 = 64 dependent s_add, 22 = 4 global_load_lds_dwordx4 (1 KiB each, L2-resident source) with a counted wait,
@@ -142,7 +204,7 @@ __global__ void k(float* out, long long* cyc, int iters) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     v[0] += (float)(vx + sacc);
   }
-  if (KIND >= 30) {
+  if (KIND >= 30 && KIND < 40) {
     // the 64-query-rows-per-wave attention tile as an instruction mix: per iteration 32 MFMAs, each followed by its gap's fillers.
     // 30: 2 exp2 + 4 plain per gap (the full softmax of two 32-row tiles: 64 exp2 + 128 plain);  31: 2 exp2 + 2 plain per gap
     // (row sums on the matrix pipe, no row maximum);  32: as 30 with 4 accumulators round-robin;  33: 1 exp2 + 2 plain per gap
@@ -194,8 +256,14 @@ void run(const char* name, int per_iter) {
   for (int wps = 1; wps <= 4; ++wps) {      // waves per SIMD: block of 256*wps threads, one block per CU
     const int threads = 256 * wps, iters = 200;
     hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float wall_ms = 0.f;
+    hipEventElapsedTime(&wall_ms, e0, e1);
     const int wpb = threads / 64;
     std::vector<long long> h(2 * 256 * wpb);
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
@@ -211,11 +279,20 @@ void run(const char* name, int per_iter) {
     }
     own /= 256.0 * wpb;
     std::sort(span.begin(), span.end());
-    printf("%-52s %d waves/SIMD: %8.1f cycles per SIMD (block makespan / (iters x waves per SIMD)), %8.1f waited by a wave\n", name, wps,
-           span[128] / ((double)iters * per_iter * wps), own / ((double)iters * per_iter));
+    printf("%-52s %d waves/SIMD: %8.1f cycles per SIMD (block makespan / (iters x waves per SIMD)), %8.1f waited by a wave, launch %7.1f us\n", name, wps,
+           span[128] / ((double)iters * per_iter * wps), own / ((double)iters * per_iter), wall_ms * 1e3);
   }
 }
 int main() {
+  if (getenv("MFMA_SHAPES")) {      // round 4: 32x32x16 against 16x16x32 at equal FLOPs and equal vector work, per iteration
+    run<12>("phase: 16 mfma 32x32x16 (per iteration)", 1);
+    run<40>("phase: 32 mfma 16x16x32 (per iteration)", 1);
+    run<10>("phases: 16 mfma32 | 96 plain + 32 exp2 (per iteration)", 1);
+    run<41>("phases: 32 mfma16 | 96 plain + 32 exp2 (per iteration)", 1);
+    run<43>("16 x (1 mfma32, 2 exp2, 6 plain) (per iteration)", 1);
+    run<42>("16 x (2 mfma16, 2 exp2, 6 plain) (per iteration)", 1);
+    return 0;
+  }
   run<0>("v_exp_f32", 16); run<1>("v_add_f32", 16); run<5>("v_rcp_f32", 16); run<2>("v_exp + v_add (pairs)", 32);
   run<4>("mfma 32x32x16 alone", 4); run<3>("4 v_exp per mfma (count exp)", 16);
   run<9>("mfma, 2 accumulators (per mfma)", 8);
