@@ -22,6 +22,19 @@
 #define KB 64
 // online softmax: the running reference of a query row moves only when a score exceeds it by more than this (log2 units)
 #define ATTN_DEFER_THR 8.0f
+// pre-scaled-q kernel: the row maximum is taken only when a tile's row sums say the running reference is stale (see LAZY in k_attn_bf16)
+#ifndef ATTN_LAZY
+#define ATTN_LAZY 1
+#endif
+#ifndef ATTN_DMA_LATE
+#define ATTN_DMA_LATE 1
+#endif
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0     // measured neutral either way (profiles/r04_attn_variants.txt); 1: the softmax phase of a wave runs at raised issue priority (s_setprio), 2: the MFMA phases do, 0: neither
+#endif
+#define ATTN_LAZY_LOG2 30
+#define ATTN_LAZY_BIG 1073741824.0f
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -98,6 +111,20 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* lds_ptr) {
 //     2 304 entries, profiles/r03_attn_staircase.txt) and the last blocks to start run on nearly empty SIMDs (the tail);
 //   * a persistent walk of the table by 768 resident blocks (tried, tests green) is no faster, 63.4 vs 61.5 us: a fresh block's
 //     prologue is 0.8 us and its epilogue + store acknowledgement 2.5 us of 29 us, and other blocks issue meanwhile.
+// Round 4 (tools/ubench/valu_rates.hip PINGPONG=1, tools/ubench/lds_rates.hip; profiles/r04_pingpong.txt, r04_lds_rates.txt,
+// r04_attn_variants.txt):
+//   * matrix and vector work of DIFFERENT waves of a SIMD do not overlap: two waves of one block run in forced anti-phase (one
+//     issues its 16 MFMAs while the other issues its vector phase, block barriers between phases) need 1 155 cycles per phase
+//     for 514 cycles of MFMAs beside ~510 of vector work - the sum -, unsynchronised co-resident waves 780-900 per unit.  Only
+//     vector instructions placed behind an MFMA in the SAME wave run under it (43-46 cycles per MFMA + 2 exp2 + 6 plain).  So
+//     per unit a SIMD of this kernel pays MFMA issue (512) + vector issue serially: 885 cycles measured, and a wave's softmax is
+//     what the loop can still shed;
+//   * the loop's LDS fragment traffic (8 ds_read_b128 + 16 ds_read_b64_tr_b16 per tile and wave) takes ~310 cycles per unit and
+//     SIMD at the 210-240 bytes / cycle / CU the part delivers: a third of the loop, not its bound;
+//   * hence LAZY below (no row maximum per tile; 113 -> 76 vector instructions per tile with the packed row sums): -5 % at the
+//     benchmark's score spread, -12 % at a spread of 6 (where the deferred reference still moved).  Four blocks per CU on 128
+//     registers (+3 %), the next tile's DMA behind the score MFMAs instead of behind the barrier, s_setprio by phase in either
+//     direction: neutral to worse, same box.
 // Everything off the wave's chain of dependent phases that could be moved has been:
 //   * the running reference of the softmax moves only when a score exceeds it by more than `defer_thr` (see below);
 //   * the DMA source of a tile is a scalar base (advanced per tile on the scalar unit) plus lane-constant offsets: no per-tile
@@ -255,6 +282,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + KB - 1) / KB;
+  constexpr bool LAZY = PRE && ATTN_LAZY;
   TL_MARK(1);
   if (mode == 0) {
   // PRE: start vectors of the two score accumulators = -m_run per lane (query); one per chain, so that neither MFMA chain has
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
     STAMP(0);                             // segment 0: wait for this wave's own DMA
     __syncthreads();                      // tile complete; every wave is done with the other stage
     STAMP(1);                             // segment 1: barrier
-    if (kt + 1 < nkt) DMA_TILE(kt + 1, buf ^ 1);
+    if (!ATTN_DMA_LATE && kt + 1 < nkt) DMA_TILE(kt + 1, buf ^ 1);
     const char* kt_lds = kbase_lds + buf * (KB * 128);
     const char* vt_lds = vbase_lds + buf * (KB * 128);
 
@@ -290,7 +318,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
     // all 8 K fragments of the tile are requested before the first MFMA (left to itself the compiler issues each read right
     // in front of its MFMA and waits for it: 8 exposed LDS latencies per tile)
     f32x16 s_acc[2];
-    {
+    auto scores = [&]() {
       bf16x8 kf[2][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -319,23 +347,20 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, PRE ? 6 : 8, 0);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    STAMP(2);                             // segment 2: DMA issue, K fragment reads, S MFMA issue
-    // mask keys past the end of the sequence (last tile only)
-    if (kt * KB + KB > S) {
+      // mask keys past the end of the sequence (last tile only)
+      if (kt * KB + KB > S) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = kt * KB + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (key >= S) s_acc[t][e] = -INFINITY;
-        }
-    }
-    // ---- online softmax (fp32) ----
-    // four independent chains (a single chain of 16 dependent v_max3 is pure latency for a wave that has nothing else to issue),
-    // then the two lane halves of a query exchange their maxima with one v_permlane32_swap (no LDS round trip)
-    float mx;
-    {
+          for (int e = 0; e < 16; ++e) {
+            const int key = kt * KB + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (key >= S) s_acc[t][e] = -INFINITY;
+          }
+      }
+    };
+    // row maximum of the tile's scores: four independent chains (a single chain of 16 dependent v_max3 is pure latency for a wave
+    // that has nothing else to issue), then the two lane halves of a query exchange their maxima with one v_permlane32_swap
+    auto row_max = [&]() -> float {
       float c4[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -347,45 +372,93 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
       }
       const float m2 = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
       const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2), __builtin_bit_cast(unsigned, m2), false, false);
-      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    }
-#ifdef ATTN_STAMPS
-    asm volatile("" ::"v"(mx));
-#endif
-    STAMP(3);                             // segment 3: S MFMA completion, row maximum, lane exchange
-    if (PRE) {
-      // the tile's scores are relative to the running reference m_run (they started from -m_run).  The reference only has to keep
-      // exp2(score - m_run) in range, it need not be the exact maximum: it is moved up only when some score of the tile exceeds it
-      // by more than defer_thr (p <= 2^thr; bf16 P keeps its 8 significant bits at any magnitude, sums are fp32).  With the
-      // exact maximum as reference, one of a wave's 32 queries meets a new maximum in most tiles (1 - (1 - 1/(kt+1))^32) and the
-      // whole wave pays the 80-instruction shift of scores, sums and accumulators nearly every tile.
-      if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0ull) {
-        const float d = kt == 0 ? mx - m_run : fmaxf(mx, 0.f);      // first tile: m_run is the placeholder 0
-        const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-d);   // nothing accumulated yet on the first tile
-        if (MSUM) o_sum[0] *= alpha; else l_run *= alpha;           // rows 1.. of the third tile are zero
+      return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    };
+    // PRE: move the running reference up to the tile's maximum mx (relative to the current reference): scores, sums, O and the start
+    // vector of the score accumulators shift with it
+    auto shift_reference = [&](const float mx) {
+      const float d = kt == 0 ? mx - m_run : fmaxf(mx, 0.f);      // first tile: m_run is the placeholder 0
+      const float alpha = kt == 0 ? 1.f : __builtin_amdgcn_exp2f(-d);   // nothing accumulated yet on the first tile
+      if (MSUM) o_sum[0] *= alpha; else l_run *= alpha;           // rows 1.. of the third tile are zero
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) s_acc[t][e] -= d;
-        m_run += d;
+        for (int e = 0; e < 16; ++e) s_acc[t][e] -= d;
+      m_run += d;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) negm0[e] = -m_run;
-      }
+      for (int e = 0; e < 16; ++e) negm0[e] = -m_run;
+    };
+    // p = exp2(score) in place; returns the lane's sum over its 32 keys.  Two packed chains: v_pk_add_f32 takes two p per
+    // instruction (16 instead of 32 adds per tile)
+    auto exp_and_sum = [&]() -> float {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) s_acc[t][e] = __builtin_amdgcn_exp2f(s_acc[t][e]);
+      f32x2 ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          ps0 += (f32x2){s_acc[t][e], s_acc[t][e + 1]};
+          ps1 += (f32x2){s_acc[t][e + 2], s_acc[t][e + 3]};
+        }
+      ps0 += ps1;
+      return ps0[0] + ps0[1];
+    };
+    scores();
+    // the next tile's DMA is issued BEHIND the score MFMAs: its four instructions take a wave 250-480 cycles to get accepted (one
+    // address path per CU, 64 bytes a cycle: tools/ubench/valu_rates.hip kind 22, profiles/r03_attn_stamps.txt) - time in which the
+    // MFMAs already run instead of waiting behind it
+    if (ATTN_DMA_LATE && kt + 1 < nkt) DMA_TILE(kt + 1, buf ^ 1);
+    if (ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+    if (ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    STAMP(2);                             // segment 2: DMA issue, K fragment reads, S MFMA issue
+    // ---- online softmax (fp32) ----
+    float psum;
+    if (PRE) {
+      // the tile's scores are relative to the running reference m_run (they started from -m_run).  The reference only has to keep
+      // exp2(score - m_run) in range, it need not be the exact maximum (bf16 P keeps its 8 significant bits at any magnitude, sums
+      // are fp32).  With the exact maximum as reference, one of a wave's 32 queries meets a new maximum in most tiles
+      // (1 - (1 - 1/(kt+1))^32) and the whole wave pays the 80-instruction shift of scores, sums and accumulators nearly every tile.
+      if (LAZY) {
+        // no row maximum per tile at all: the scores are exponentiated against the reference as it stands, and the row sums - needed
+        // anyway - tell whether that was safe.  A lane whose 32 p's sum to more than 2^ATTN_LAZY_LOG2 (or to inf / NaN) sends the wave
+        // through the tile again (K is still in LDS), this time with the exact maximum and the shift.  Only an entry's first tile
+        // (no reference yet) and such tiles pay the ~26 vector instructions of the maximum.
+        // (one site for the shift: a second one makes hipcc carry the 16-register start vector through copies on the hot path)
+        bool exact = kt == 0;
+        if (!exact) {
+          psum = exp_and_sum();
+          exact = __builtin_amdgcn_ballot_w64(!(psum <= ATTN_LAZY_BIG)) != 0ull;
+          if (exact) scores();
+        }
+        STAMP(3);
+        if (exact) {
+          shift_reference(row_max());
+          psum = exp_and_sum();
+        }
+      } else {
+        // the reference is moved up only when some score of the tile exceeds it by more than defer_thr (p <= 2^thr)
+        const float mx = row_max();
+        STAMP(3);                           // segment 3: S MFMA completion, row maximum, lane exchange
+        if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0ull) shift_reference(mx);
+        psum = exp_and_sum();
+      }
     } else {
+      const float mx = row_max();
+      STAMP(3);
       const float m_new = (mx - m_run) * c_exp > defer_thr ? mx : m_run;   // deferred reference (see the PRE branch); the -inf start moves
       const float mc = m_new * c_exp;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s_acc[t][e] = __builtin_amdgcn_exp2f(fmaf(s_acc[t][e], c_exp, -mc));
+        for (int e = 0; e < 16; ++e) s_acc[t][e] = fmaf(s_acc[t][e], c_exp, -mc);
+      psum = exp_and_sum();
       // rescale the running state only when some row's reference moved (wave-uniform branch; exact: alpha == 1 otherwise)
       if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
@@ -397,14 +470,7 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
         m_run = m_new;
       }
     }
-    if (!MSUM) {
-      float psum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) psum += s_acc[t][e];
-      l_run += psum;
-    }
+    if (!MSUM) l_run += psum;
     // P as bf16 B-operand fragments: k-step (t, sp) = registers 8sp..8sp+7 of score tile t
 #define PFRAG(t_, sp_)                                                                                             \
   ((bf16x8){(bf16_t)s_acc[t_][8 * sp_ + 0], (bf16_t)s_acc[t_][8 * sp_ + 1], (bf16_t)s_acc[t_][8 * sp_ + 2],        \
@@ -415,6 +481,8 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
 #ifdef ATTN_STAMPS
     asm volatile("" ::"v"(pf00), "v"(pf01), "v"(pf10), "v"(pf11));
 #endif
+    if (ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     STAMP(4);                             // segment 4: exp2, bf16 pack
 
     // ---- O^T += V^T P^T, row sums += 1^T P^T ----

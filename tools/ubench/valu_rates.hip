@@ -92,6 +92,52 @@ __global__ void k(float* out, long long* cyc, int iters) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (KIND >= 50 && KIND < 60) {
+    // round 4: ping-pong.  The waves of a block that share a SIMD (wave w and w + 4 of an 8-wave block) run the two phases of the
+    // attention tile in ANTI-phase, separated by block barriers: while one issues its 16 MFMAs the other issues its vector work.
+    // 50: 96 plain + 32 exp2 (the round-3 mix);  51: 44 plain + 32 exp2 (the loop after round 4: no row maximum, packed sums);
+    // 52 / 53: the same two without the barriers and without the anti-phase start (what unsynchronised co-resident waves do)
+    // 54 / 55: as 51 / 53 with s_setprio 2 around the VECTOR phase;  56 / 57: with s_setprio 2 around the MFMA phase
+    const int grp = (threadIdx.x >> 8) & 1;
+    constexpr int NP = (KIND == 50 || KIND == 52) ? 3 : 1;
+    constexpr bool SYNC = KIND == 50 || KIND == 51 || KIND == 54 || KIND == 56;
+    constexpr int PRIO = (KIND == 54 || KIND == 55) ? 1 : (KIND == 56 || KIND == 57) ? 2 : 0;      // plain per exp2 (+ 12 more below for 51 / 53)
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const bool mfma_phase = !SYNC ? (ph == 0) : ((ph ^ grp) == 0);
+        if (mfma_phase) {
+          if (PRIO == 2) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          }
+          if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        } else {
+          if (PRIO == 1) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              v[i] = __builtin_amdgcn_exp2f(v[i]);
+              w[i] = w[i] + 1.25f;
+              if (NP == 3) {
+                w[(i + 5) & 15] = w[(i + 5) & 15] * 0.75f;
+                w[(i + 9) & 15] = w[(i + 9) & 15] + 0.5f;
+              }
+            }
+          if (NP == 1) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) w[i] = w[i] * 0.75f;
+          }
+          if (PRIO == 1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (SYNC) __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
   if (KIND >= 40 && KIND < 43) {
     // round 4: the same FLOPs on v_mfma_f32_16x16x32_bf16 (two of them per 32x32x16: 32 per iteration), same vector work:
     // 40 = the MFMAs alone, 41 = phases (32 mfma16 | 96 plain + 32 exp2), 42 = interleaved 16 x (2 mfma16, 2 exp2, 6 plain).
@@ -284,6 +330,17 @@ void run(const char* name, int per_iter) {
   }
 }
 int main() {
+  if (getenv("PINGPONG")) {         // round 4: anti-phase waves of one block against unsynchronised ones, per iteration (= per unit and wave)
+    run<52>("unsynchronised: 16 mfma | 96 plain + 32 exp2 (per iteration)", 1);
+    run<50>("ping-pong:      16 mfma | 96 plain + 32 exp2 (per iteration)", 1);
+    run<53>("unsynchronised: 16 mfma | 44 plain + 32 exp2 (per iteration)", 1);
+    run<51>("ping-pong:      16 mfma | 44 plain + 32 exp2 (per iteration)", 1);
+    run<55>("unsynchronised, vector phase at priority 2 (44 plain mix)", 1);
+    run<54>("ping-pong,      vector phase at priority 2 (44 plain mix)", 1);
+    run<57>("unsynchronised, MFMA phase at priority 2 (44 plain mix)", 1);
+    run<56>("ping-pong,      MFMA phase at priority 2 (44 plain mix)", 1);
+    return 0;
+  }
   if (getenv("MFMA_SHAPES")) {      // round 4: 32x32x16 against 16x16x32 at equal FLOPs and equal vector work, per iteration
     run<12>("phase: 16 mfma 32x32x16 (per iteration)", 1);
     run<40>("phase: 32 mfma 16x16x32 (per iteration)", 1);
