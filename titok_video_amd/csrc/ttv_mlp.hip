@@ -397,7 +397,12 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
             gg[4 * i + e] = acc1[2 + i][j][e] * rstd[j];
             xx[4 * i + e] = acc1[i][j][e] * rstd[j];
           }
-        geglu_fast8(gg, xx, hh);
+        if (p.debug & 4) {      // diagnostic (tools/mlp_ablate.py): no GEGLU arithmetic, garbage results
+#pragma unroll
+          for (int k = 0; k < 8; ++k) hh[k] = gg[k] + xx[k];
+        } else {
+          geglu_fast8(gg, xx, hh);
+        }
         uint32_t hw[4];
         typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll

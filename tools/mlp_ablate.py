@@ -16,7 +16,7 @@ def t(fn,it=20):
     e0.record()
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1)*1e3/it
-for dbg in [0,1,2,4,16,32,4|16,4|32,16|32,2|4|16|32, 2|4|16|32|1]:
+for dbg in [0, 1, 2, 4, 16, 4 | 16, 2 | 4 | 16, 0]:      # 1: no stores, 2: no weight DMA after the first panel, 4: no GEGLU arithmetic, 16: no P2 MFMAs
     lib.ttv_debug_set(dbg)
     print(f"debug {dbg:3d}: {t(lambda: lib.ttv_mlp_fused(x.data_ptr(),d,mp.data_ptr(),I,yb.data_ptr(),d,gain.data_ptr(),8.0,1e-5,L,d,0,S)):7.1f} us", flush=True)
 lib.ttv_debug_set(0)
