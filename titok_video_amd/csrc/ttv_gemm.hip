@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       tok[j] = tile * K256_TT + wave * 32 + j * 16 + l15;
-      if (PRENORM) {
+      if (PRENORM && !(p.debug & 8)) {     // debug bit 8 (tools/qkv_ablate.py): no epilogue arithmetic - timing only, garbage results
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] *= rstd[j];
       }
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
 #pragma unroll
       for (int i = 0; i < 4; ++i) feat[i] = panel * FO + i * 16 + kq * 4;
       const int f_first = panel * FO;
-      if (f_first < p.rope_q_end || (f_first >= p.rope_k_begin && f_first < p.rope_k_end)) {
+      if (!(p.debug & 8) && (f_first < p.rope_q_end || (f_first >= p.rope_k_begin && f_first < p.rope_k_end))) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
