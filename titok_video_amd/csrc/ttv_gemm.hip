@@ -2030,7 +2030,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split_dma(GemmDev p, int n_ftil
 
 template <int EPI>
 static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
-  if (dtype == TTV_BF16 && d.K == 256 && d.N % 8 == 0) {
+  // debug bit 16384 (diagnostics): send a K = 256 GEMM through the general-K kernels instead (no folded pre-norm, no patch scatter there)
+  if (dtype == TTV_BF16 && d.K == 256 && d.N % 8 == 0 && !((d.debug & 16384) && !prenorm && EPI != EPI_STORE_PATCH)) {
     const int fo = (EPI == EPI_GEGLU) ? 32 : 64;
     const int n_panels = ttv_cdiv(d.N, fo), n_tiles = ttv_cdiv(d.M, K256_TT);
     const int total = n_panels * n_tiles;

@@ -37,6 +37,16 @@ if [ $PART = r04base ]; then
   step base5 rocprof; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_base5 -o p -- python3 $R/bench.py --config base5 --in-flight 1 --no-cpu-baseline --no-fp32-leg > $O/base5_bench_inflight1_under_rocprof.json 2> $O/prof_base5.log
   find $O -name "*kernel_trace.csv" -delete
 fi
+if [ $PART = r04attn ]; then   # the attention kernel alone: stamps, timeline, both shapes, three SQ counter passes (diagnostic builds: tools/attn_stamps.sh, attn_timeline.sh)
+  step stamps; TTV_LIB_PATH=$R/titok_video_amd/csrc/build/libtitok_hip_stamps.so timeout -k 10 200 python3 $R/tools/attn_stamps.py > $O/attn_stamps.txt 2>&1
+  step timeline; TTV_LIB_PATH=$R/titok_video_amd/csrc/build/libtitok_hip_timeline.so timeout -k 10 200 python3 $R/tools/attn_timeline.py > $O/attn_timeline.txt 2>&1
+  step attention alone; FP32=0 timeout -k 10 200 python3 $R/tools/attn_bench.py 1.5 6 > $O/attn_bench.txt 2>&1
+  B=4 CLIP=32,256,256 K=1024 HQ=12 HKV=4 FP32=0 timeout -k 10 200 python3 $R/tools/attn_bench.py 1.5 >> $O/attn_bench.txt 2>&1
+  for i in 1 2 3; do
+    case $i in 1) C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY";; 2) C="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA";; 3) C="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE";; esac
+    step sq pass $i: $C; FP32=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/sq$i -o s -- python3 $R/tools/attn_bench.py 1.5 > /dev/null 2> $O/sq$i.log
+  done
+fi
 if [ $PART = tiny ]; then
   step bench default; python3 $R/bench.py > $O/tiny_bench.json 2> $O/tiny_bench.err
   step bench in-flight 1; python3 $R/bench.py --in-flight 1 --no-cpu-baseline > $O/tiny_bench_inflight1.json 2>> $O/tiny_bench.err
