@@ -52,6 +52,7 @@ struct GemmDev {
   int ld_mx;
   uint8_t* yq; uint8_t* yq_mx; int ld_yq_mx, yq_nkp;   // EPI_GEGLU of the MX kernel: h leaves as block-scaled e4m3 [M, N] + scales instead of bf16
   int clip0, pt_shift, ph_shift;   // log2(patch_t), log2(patch_h); patch_w == 8
+  long long* stamps;               // diagnostic builds only (-DQKV_STAMPS): g_ttv_stamps
 };
 
 // per-token part of a patch destination (EPI_STORE_PATCH), computed once per token tile
@@ -1372,6 +1373,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
 #undef MFMA8
 }
 
+#include "ttv_qkv256.inc"
+
 // ================================================================================================
 // out_proj of a width-256 tower fused with the whole KEEL step (transformer.py:141-142):
 //     x_new = RMSNorm(alpha * x + ao @ Wo^T) * gain          (K == 256, N == 256, bf16)
@@ -2048,6 +2051,18 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     else if (total > 512)
       for (int g = 512; g >= 416; --g)
         if (total % g == 0) { grid = g; break; }
+    // to_qkv: the wave-pipelined kernel (ttv_qkv256.inc) unless the call needs something only the general epilogue has;
+    // TTV_QKV256=0 / ttv_debug_set bit 15 (32768): k_gemm_k256's QKV instantiation (A/B, tests)
+    static const bool qkv256_env = !(getenv("TTV_QKV256") && getenv("TTV_QKV256")[0] == '0');
+    if constexpr (EPI == EPI_QKV_ROPE) {
+      if (qkv256_env && !(d.debug & 32768) && d.N % 64 == 0 && d.rope_q_end % 64 == 0 && d.rope_k_begin % 64 == 0 && d.rope_k_end % 64 == 0 &&
+          !d.row_scale && !d.bias && !d.add_scalar && (uint64_t)d.w_rows * (uint64_t)d.ldw * 2u < (1ull << 32)) {
+        if (prenorm) hipLaunchKernelGGL((k_qkv256<true>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
+        else hipLaunchKernelGGL((k_qkv256<false>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
+        TTV_CHECK_LAUNCH("qkv256");
+        return TTV_OK;
+      }
+    }
     if (prenorm) hipLaunchKernelGGL((k_gemm_k256<EPI, true>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
     else hipLaunchKernelGGL((k_gemm_k256<EPI, false>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
     TTV_CHECK_LAUNCH("gemm_k256");
@@ -2204,6 +2219,7 @@ int ttvk_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   d.x_rows = a.x_rows;
   d.x_scale = nullptr; d.w_scale = nullptr;
   d.row_scale = a.row_scale;
+  d.stamps = g_ttv_stamps;
   TTV_CHECK_ARG(!a.row_scale || ((a.dtype == TTV_BF16 || a.split3) && (epi == EPI_STORE || epi == EPI_QKV_ROPE || epi == EPI_GEGLU)),
                 "gemm: row_scale is a STORE / QKV_ROPE / GEGLU option of the bf16 and the split-bf16 kernels");
   TTV_CHECK_ARG(!a.x_rows || (a.dtype == TTV_BF16 && a.K == 256 && a.N % 8 == 0 && epi != EPI_RESID_NORM), "gemm: x_rows needs the bf16 K=256 kernel");
