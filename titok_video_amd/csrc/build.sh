@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vect
 mkdir -p build
 pids=()
 for f in ttv_elem ttv_gemm ttv_attn ttv_attn64 ttv_mlp ttv_bwd ttv_train ttv_vq ttv_api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ ttv_common.h -nt build/$f.o ] || [ ttv_kernels.h -nt build/$f.o ] || { [ $f = ttv_gemm ] && [ ttv_qkv256.inc -nt build/$f.o ]; } || [ ../../include/titok_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ ttv_common.h -nt build/$f.o ] || [ ttv_kernels.h -nt build/$f.o ] || { [ $f = ttv_gemm ] && { [ ttv_qkv256.inc -nt build/$f.o ] || [ ttv_qkv256ws.inc -nt build/$f.o ]; }; } || [ ../../include/titok_hip.h -nt build/$f.o ]; then
     if [ $f = ttv_attn64 ]; then bash build_attn64.sh build/$f.o &       # two-step build: see build_attn64.sh
     else hipcc $FLAGS -c $f.hip -o build/$f.o &
     fi

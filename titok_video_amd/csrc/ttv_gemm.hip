@@ -1374,6 +1374,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
 }
 
 #include "ttv_qkv256.inc"
+#include "ttv_qkv256ws.inc"
 
 // ================================================================================================
 // out_proj of a width-256 tower fused with the whole KEEL step (transformer.py:141-142):
@@ -2051,12 +2052,26 @@ static int launch(const GemmDev& d, int dtype, bool prenorm, hipStream_t s) {
     else if (total > 512)
       for (int g = 512; g >= 416; --g)
         if (total % g == 0) { grid = g; break; }
-    // to_qkv: the wave-pipelined kernel (ttv_qkv256.inc) unless the call needs something only the general epilogue has;
-    // TTV_QKV256=0 / ttv_debug_set bit 15 (32768): k_gemm_k256's QKV instantiation (A/B, tests)
-    static const bool qkv256_env = !(getenv("TTV_QKV256") && getenv("TTV_QKV256")[0] == '0');
+    // to_qkv: the wave-pipelined streaming kernel k_qkv256 (ttv_qkv256.inc) unless the call needs something only the general epilogue
+    // has (30.3 us against k_gemm_k256's 31.2 inside the benchmark forward, profiles/r04_qkv256_inpipe.txt).  TTV_QKV256=0 / ttv_debug_set
+    // bit 15 (32768): k_gemm_k256's QKV instantiation; TTV_QKV256=2 / bit 17 (131072): the weight-stationary kernel k_qkv256ws
+    // (ttv_qkv256ws.inc; 34.2 us: measured, kept for A/B) - all three give the same bits without the folded pre-norm
+    static const int qkv256_env = getenv("TTV_QKV256") ? atoi(getenv("TTV_QKV256")) : 1;
     if constexpr (EPI == EPI_QKV_ROPE) {
+      const int n_groups = (n_panels + 3) / 4;
       if (qkv256_env && !(d.debug & 32768) && d.N % 64 == 0 && d.rope_q_end % 64 == 0 && d.rope_k_begin % 64 == 0 && d.rope_k_end % 64 == 0 &&
           !d.row_scale && !d.bias && !d.add_scalar && (uint64_t)d.w_rows * (uint64_t)d.ldw * 2u < (1ull << 32)) {
+        if ((qkv256_env >= 2 || (d.debug & 131072)) && n_groups <= 32) {
+          // one block per CU: blocks b, b + 8, .. (one XCD under round-robin dispatch) share an eighth of the 32-token groups, split between
+          // the panel groups; no more blocks than there are units for
+          const int tgs = ttv_cdiv(d.M, 32), per_xcd = ttv_cdiv(tgs, 8);
+          int q = n_groups * ttv_cdiv(per_xcd, 8);
+          q = q > 32 ? 32 : q;
+          if (prenorm) hipLaunchKernelGGL((k_qkv256ws<true>), dim3(8 * q), dim3(512), 0, s, d, n_panels, n_groups);
+          else hipLaunchKernelGGL((k_qkv256ws<false>), dim3(8 * q), dim3(512), 0, s, d, n_panels, n_groups);
+          TTV_CHECK_LAUNCH("qkv256ws");
+          return TTV_OK;
+        }
         if (prenorm) hipLaunchKernelGGL((k_qkv256<true>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
         else hipLaunchKernelGGL((k_qkv256<false>), dim3(grid), dim3(256), 0, s, d, n_panels, total);
         TTV_CHECK_LAUNCH("qkv256");

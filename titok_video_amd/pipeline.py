@@ -24,6 +24,7 @@ its references as soon as `submit` returns.  `drain()` is still the way to make 
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -50,7 +51,10 @@ class ForwardPipeline:
         self.device = device if device is not None else next(model.parameters()).device
         if torch.device(self.device).type != "cuda":
             raise RuntimeError("ForwardPipeline needs a GPU model (there is no CPU path)")
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        # TTV_PIPE_PRIO=1 (A/B): the streams get different queue priorities (the first one high), so that one chain is served first and
+        # the other fills what it leaves idle, instead of two equal queues splitting every CU
+        prio = os.environ.get("TTV_PIPE_PRIO", "0") == "1"
+        self.streams = [torch.cuda.Stream(device=self.device, priority=(-1 if (prio and i == 0) else 0)) for i in range(depth)]
         self._n = 0
 
     def submit(self, *args, **kwargs) -> Tuple[Any, torch.cuda.Event]:
