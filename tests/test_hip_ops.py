@@ -309,6 +309,34 @@ def test_linear_qkv_rope(dt):
     assert_close(y.float(), torch.cat([q, gate, k, v], -1), dt)
 
 
+@pytest.mark.parametrize("shape", ["ragged", "one_tile", "many_tiles"])
+def test_to_qkv_width256_kernels_give_the_same_bits(shape):
+    """The three kernels behind `ttv_linear_qkv_rope` at K = 256 bf16 - k_qkv256 (default: wave-pipelined, 32x32x16 MFMAs), k_qkv256ws
+    (weights stationary in LDS, ttv_debug_set bit 17) and k_gemm_k256<EPI_QKV_ROPE> (bit 15) - multiply the same operands in the same
+    k order and rotate with the same fp32 arithmetic: without the folded pre-norm their outputs are bit-identical, whatever the
+    decomposition (ragged last tile, fewer rows than one tile, several tiles per block)."""
+    shapes, counts = {"ragged": ([(8, 32, 48), (4, 16, 24), (4, 24, 40)], [3, 5, 7]), "one_tile": ([(4, 16, 16)], [2]),
+                      "many_tiles": ([(16, 64, 64)] * 5, [32] * 5)}[shape]
+    plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
+    M, d, gq = plan.total_rows, 256, 128
+    x, w, _ = _lin_inputs(M, 2 * d + 2 * gq, d, "bf16", 11)
+    xd, wd = x.to(DEV), w.to(DEV)
+    outs = []
+    try:
+        for bits in (0, 1 << 15, 1 << 17):
+            y = torch.full((M, 2 * d + 2 * gq), float("nan"), dtype=torch.bfloat16, device=DEV)
+            L().ttv_debug_set(bits)
+            _lib.check(L().ttv_linear_qkv_rope(xd.data_ptr(), d, wd.data_ptr(), d, y.data_ptr(), 2 * d + 2 * gq, M, d, gq,
+                                               plan.rope_cs.data_ptr(), _lib.dtype_code(torch.bfloat16), S()), "qkv")
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        L().ttv_debug_set(0)
+    assert not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0], outs[1]), "k_qkv256 differs from k_gemm_k256"
+    assert torch.equal(outs[2], outs[1]), "k_qkv256ws differs from k_gemm_k256"
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("I", [704, 1376, 96])
 def test_linear_geglu(dt, I):
