@@ -17,6 +17,7 @@ import os
 
 CLASS_OF = (            # kernel-name fragment -> bench.py --kernel class
     ("k_attn_bf16<", "attention"),
+    ("k_qkv256<", "gemm_qkv"),        # round 4: the wave-pipelined to_qkv kernel (k_gemm_k256<1,..> before / with TTV_QKV256=0)
     ("k_gemm_k256<1,", "gemm_qkv"),
     ("k_gemm_k256<2,", "gemm_geglu"),
     ("k_mlp256<", "layer_tail"),
