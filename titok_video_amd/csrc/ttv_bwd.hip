@@ -345,21 +345,34 @@ int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (bias grads)
+// thread -> column (grid.y tiles of 256 columns), block -> row range.  Eight rows in flight per thread (independent partial sums):
+// with one running sum the 128 rows of a block were 128 dependent load -> add steps and the launch took ~30 us whatever the batch
+// (latency, not bytes: 6 launches per training step); the partial sums are combined in a fixed order, rows past the end add zero.
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ a, int lda, const int* __restrict__ rows_map, int rows, int n,
                                                 float* __restrict__ out, int rows_per_block) {
-  // thread -> column (grid.y tiles of 256 columns), block -> row range
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= n) return;
   const int r0 = blockIdx.x * rows_per_block;
-  float acc = 0.f;
-  for (int r = r0; r < r0 + rows_per_block && r < rows; ++r) acc += Cvt<T>::to_f(a[(size_t)(rows_map ? rows_map[r] : r) * lda + c]);
-  atomicAdd(out + c, acc);
+  const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = r + u < r1 ? r + u : r1 - 1;
+      v[u] = Cvt<T>::to_f(a[(size_t)(rows_map ? rows_map[rr] : rr) * lda + c]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += r + u < r1 ? v[u] : 0.f;
+  }
+  atomicAdd(out + c, ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
 }
 
 int ttvk_colsum(const void* a, int dt, int lda, const int* rows_map, int rows, int n, float* out, hipStream_t s) {
   if (rows == 0 || n == 0 || !out) return TTV_OK;   // out == NULL: this parameter's gradient is not wanted
-  const int rpb = 128;
+  // narrow matrices (n <= 256: one column tile) are latency-bound per block: shorter row ranges, more blocks
+  const int rpb = 64;
   dim3 grid(ttv_cdiv(rows, rpb), ttv_cdiv(n, 256));
   if (dt == TTV_BF16) hipLaunchKernelGGL((k_colsum<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)a, lda, rows_map, rows, n, out, rpb);
   else hipLaunchKernelGGL((k_colsum<float>), grid, dim3(256), 0, s, (const float*)a, lda, rows_map, rows, n, out, rpb);
@@ -945,17 +958,28 @@ template <typename TA, typename TB>
 __global__ __launch_bounds__(256) void k_outer_small(const TA* __restrict__ a, int lda, int C, const TB* __restrict__ b, int ldb,
                                                      const int* __restrict__ b_rows, float* __restrict__ dw, int lddw, int transpose_out,
                                                      int rows, int d, int rows_per_block) {
-  // thread -> feature f (d <= 1024: loop), accumulates C partial sums over the block's rows
+  // thread -> feature f (d <= 1024: loop), accumulates C partial sums over the block's rows; four rows in flight (the row loop was one
+  // dependent load -> fma chain per row: ~36 us per launch at any batch size)
   const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   for (int f = threadIdx.x; f < d; f += 256) {
     float acc[TTV_MAX_FSQ];
 #pragma unroll
     for (int c = 0; c < TTV_MAX_FSQ; ++c) acc[c] = 0.f;
-    for (int r = r0; r < r0 + rows_per_block && r < rows; ++r) {
-      const float bv = Cvt<TB>::to_f(b[(size_t)(b_rows ? b_rows[r] : r) * ldb + f]);
+    for (int r = r0; r < r1; r += 4) {
+      float bv[4];
 #pragma unroll
-      for (int c = 0; c < TTV_MAX_FSQ; ++c)
-        if (c < C) acc[c] += Cvt<TA>::to_f(a[(size_t)r * lda + c]) * bv;
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u < r1 ? r + u : r1 - 1;
+        bv[u] = r + u < r1 ? Cvt<TB>::to_f(b[(size_t)(b_rows ? b_rows[rr] : rr) * ldb + f]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u < r1 ? r + u : r1 - 1;
+#pragma unroll
+        for (int c = 0; c < TTV_MAX_FSQ; ++c)
+          if (c < C) acc[c] += Cvt<TA>::to_f(a[(size_t)rr * lda + c]) * bv[u];
+      }
     }
 #pragma unroll
     for (int c = 0; c < TTV_MAX_FSQ; ++c)
@@ -967,7 +991,7 @@ int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int
                      int transpose_out, int rows, int d, hipStream_t s) {
   if (rows == 0 || !dw) return TTV_OK;
   TTV_CHECK_ARG(C >= 1 && C <= TTV_MAX_TOKEN, "outer_small: C");
-  const int rpb = 64;
+  const int rpb = 32;
   dim3 grid(ttv_cdiv(rows, rpb));
   // the kernel keeps TTV_MAX_FSQ partial sums per thread: wider tokens (the L2 quantiser's, up to TTV_MAX_TOKEN) go in column chunks
   for (int c0 = 0; c0 < C; c0 += TTV_MAX_FSQ) {
