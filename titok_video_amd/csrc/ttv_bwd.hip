@@ -18,6 +18,11 @@
 #include "ttv_kernels.h"
 
 #define BW_MAX_ITERS 4
+#define BW_TRY(expr)                 \
+  do {                               \
+    const int rc__ = (expr);         \
+    if (rc__ != TTV_OK) return rc__; \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------ rmsnorm backward
 template <typename TX, typename TG, typename TO>
@@ -869,6 +874,71 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
+// The same sum for up to TTV_WGRAD_BATCH weight gradients in one launch (ttvk_wgrad_flush): block -> (entry, tile, fragment) through the
+// entries' block prefix; arithmetic and order per element are k_wgrad_reduce's (bit-identical gradients).  At the reference's batch
+// sizes a reduce launch is ~7.5 us of latency for microseconds of work and a training step had 34 of them.
+struct WgradBatchDev {
+  int n;
+  int first_block[TTV_WGRAD_BATCH + 1];
+  WgradBatch::Entry e[TTV_WGRAD_BATCH];
+};
+__global__ __launch_bounds__(256) void k_wgrad_reduce_multi(WgradBatchDev b) {
+  __shared__ f32x4 red[3][64];
+  int ei = 0;
+#pragma unroll
+  for (int i = 1; i < TTV_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_block[i]) ei = i;
+  const WgradBatch::Entry en = b.e[ei];
+  const int blk = blockIdx.x - b.first_block[ei];
+  const int tile = blk >> 6, frag = blk & 63, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int wave = frag >> 4, i = (frag >> 2) & 3, j = frag & 3, l15 = lane & 15, kq = lane >> 4;
+  const int splits = en.splits;
+  const int per = (splits + 3) >> 2;
+  const int s0 = grp * per, s1 = min(splits, s0 + per);
+  const f32x4* src = reinterpret_cast<const f32x4*>(en.part) + (size_t)tile * splits * 4096 + frag * 64 + lane;
+  f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int sp = s0;
+  for (; sp + 8 <= s1; sp += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sp + u) * 4096];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; sp < s1; ++sp) sum += src[(size_t)sp * 4096];
+  if (grp) red[grp - 1][lane] = sum;
+  __syncthreads();
+  if (grp) return;
+  sum += red[0][lane];
+  sum += red[1][lane];
+  sum += red[2][lane];
+  const int n0 = (tile % en.tiles_n) * 128, k0 = (tile / en.tiles_n) * 128;
+  const int kk = k0 + (wave >> 1) * 64 + j * 16 + l15;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int nn = n0 + (wave & 1) * 64 + i * 16 + kq * 4 + e;
+    if (nn < en.N && kk < en.K) en.dw[(size_t)nn * en.lddw + kk] += sum[e];
+  }
+}
+
+int ttvk_wgrad_flush(WgradBatch* batch, hipStream_t s) {
+  if (!batch || batch->n == 0) return TTV_OK;
+  WgradBatchDev d = {};
+  d.n = batch->n;
+  int blocks = 0;
+  for (int i = 0; i < batch->n; ++i) {
+    d.first_block[i] = blocks;
+    d.e[i] = batch->e[i];
+    blocks += batch->e[i].tiles * 64;
+  }
+  d.first_block[batch->n] = blocks;
+  hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(blocks), dim3(256), 0, s, d);
+  batch->n = 0;
+  batch->used_bytes = 0;
+  TTV_CHECK_LAUNCH("wgrad_reduce_multi");
+  return TTV_OK;
+}
+
 // naive fp32 variant (gradient checks): thread per output element, block 16 x 16, token range per blockIdx.z
 __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                    float* __restrict__ dw, int lddw, int L, int N, int K, int tokens_per_block) {
@@ -914,8 +984,10 @@ int64_t ttvk_wgrad_ws_bytes(int L, int N, int K) {
 }
 
 int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, float* part,
-               int64_t part_bytes, hipStream_t s) {
+               int64_t part_bytes, hipStream_t s, WgradBatch* batch) {
   if (L == 0 || N == 0 || K == 0 || !dw) return TTV_OK;   // dw == NULL: frozen weight
+  static const bool batch_env = !(getenv("TTV_WGRAD_BATCHED") && getenv("TTV_WGRAD_BATCHED")[0] == '0');   // A/B
+  if (!batch_env && batch) { BW_TRY(ttvk_wgrad_flush(batch, s)); batch = nullptr; }
   if (dt == TTV_BF16 && N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0) {
     static const int wg_tile64 = getenv("TTV_WGRAD_TILE64") ? 1 : 0;
     if (!wg_tile64 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0)) {
@@ -923,7 +995,18 @@ int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int 
       wgrad_plan(L, N, K, &splits, &tpb);
       const int tn = ttv_cdiv(N, 128), tk = ttv_cdiv(K, 128);
       dim3 grid(tn * tk * (splits >= 8 ? 8 * ttv_cdiv(splits, 8) : splits));
-      if (part && part_bytes >= (int64_t)tn * tk * splits * 65536 && ((uintptr_t)part % 16 == 0)) {
+      const int64_t need = (int64_t)tn * tk * splits * 65536;
+      if (batch && part && ((uintptr_t)part % 16 == 0) && (batch->n == TTV_WGRAD_BATCH || batch->used_bytes + need > part_bytes))
+        BW_TRY(ttvk_wgrad_flush(batch, s));        // does not fit behind what is pending: sum that first, start over at the scratch's base
+      if (batch && part && ((uintptr_t)part % 16 == 0) && batch->used_bytes + need <= part_bytes) {
+        float* mine = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + batch->used_bytes);
+        hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
+                           tpb, mine, tn, tk, splits);
+        WgradBatch::Entry& en = batch->e[batch->n++];
+        en.part = mine; en.dw = dw; en.splits = splits; en.lddw = lddw; en.N = N; en.K = K; en.tiles_n = tn; en.tiles = tn * tk;
+        batch->used_bytes += need;
+      } else if (part && part_bytes >= need && ((uintptr_t)part % 16 == 0)) {
+        if (batch) BW_TRY(ttvk_wgrad_flush(batch, s));
         hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
                            tpb, part, tn, tk, splits);
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(tn * tk * 64), dim3(256), 0, s, part, splits, dw, lddw, N, K, tn);

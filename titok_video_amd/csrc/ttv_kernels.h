@@ -152,8 +152,19 @@ int ttvk_scale_cast(const float* a, float alpha, float* b, void* c, int dt, long
 int ttvk_to_f32(const void* a, int dt, float* b, long n, int accumulate, hipStream_t s);
 int ttvk_fsq_bwd(const ttv_fsq_params* fp, const float* z, const void* dcodes, int dt, float* dz, int rows, hipStream_t s);
 // part / part_bytes: optional scratch for the split partial tiles (ttvk_wgrad_ws_bytes); without it the bf16 path uses fp32 atomics
+// `batch` (optional): the split partial tiles of several weight gradients are summed by ONE launch (ttvk_wgrad_flush) instead of one
+// k_wgrad_reduce per weight: the call takes its partial tiles from part + batch->used_bytes, records what to sum and returns; the
+// gradients are complete only behind the flush.  A call that does not fit (more than TTV_WGRAD_BATCH entries, scratch exhausted,
+// or a shape that takes another path) flushes what is pending and proceeds on its own.
+#define TTV_WGRAD_BATCH 6
+struct WgradBatch {
+  int n = 0;
+  int64_t used_bytes = 0;
+  struct Entry { const float* part; float* dw; int splits, lddw, N, K, tiles_n, tiles; } e[TTV_WGRAD_BATCH];
+};
 int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int lddw, int L, int N, int K, int dt, float* part,
-               int64_t part_bytes, hipStream_t s);
+               int64_t part_bytes, hipStream_t s, WgradBatch* batch = nullptr);
+int ttvk_wgrad_flush(WgradBatch* batch, hipStream_t s);
 int64_t ttvk_wgrad_ws_bytes(int L, int N, int K);
 int ttvk_outer_small(const void* a, int a_dt, int lda, int C, const void* b, int b_dt, int ldb, const int* b_rows, float* dw, int lddw,
                      int transpose_out, int rows, int d, hipStream_t s);

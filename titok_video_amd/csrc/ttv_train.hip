@@ -74,11 +74,16 @@ static BwdWs carve_bwd(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
   // split partial tiles of the weight-gradient GEMMs (largest of the shapes the tower uses)
   int64_t wgb = 0;
   if (d->dtype == TTV_BF16) {
+    // the four weight gradients of a layer keep their partial tiles side by side and are summed by one launch (WgradBatch): room for
+    // their SUM; the head / tail projections run on their own (largest single shape)
     const int64_t shapes[6][3] = {{L, dm, d->inner}, {L, 2 * d->inner, dm}, {L, dm, dm}, {L, nq, dm}, {P, dm, pd}, {P, pd, dm}};
-    for (auto& sh : shapes) {
-      const int64_t v = ttvk_wgrad_ws_bytes((int)sh[0], (int)sh[1], (int)sh[2]);
+    int64_t layer_sum = 0;
+    for (int i = 0; i < 6; ++i) {
+      const int64_t v = ttvk_wgrad_ws_bytes((int)shapes[i][0], (int)shapes[i][1], (int)shapes[i][2]);
+      if (i < 4) layer_sum += v;
       wgb = v > wgb ? v : wgb;
     }
+    wgb = layer_sum > wgb ? layer_sum : wgb;
   }
   w.wg_part = (float*)take(wgb); w.wg_part_bytes = wgb;
   w.total = off;
@@ -181,6 +186,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
   const long nLd = (long)L * dm;
   float* dx = ws.dxa;     // gradient of the layer output
   float* tmp = ws.dxb;
+  WgradBatch wgb;
   for (int i = d->layers - 1; i >= 0; --i) {
     const ttv_layer_weights& lw = w->layers[i];
     const ttv_layer_weights_t& lt = wt->layers[i];
@@ -204,13 +210,13 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     GemmArgs a = {};
     a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = L; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
     TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, L, dm, I, dt, ws.wg_part, ws.wg_part_bytes, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, L, dm, I, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
     TTV_TRY(ttvk_geglu_bwd(l.u, 2 * I, ws.g_i, I, ws.g_2i, 2 * I, L, I, dt, s));
     // dxn2 = du W12 ; dW12 += du^T xn2
     GemmArgs c = {};
     c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = L; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, c, s));
-    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
+    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
     // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2), then straight through the attention sub-layer's post-norm:
     // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
     // i > 0: dy1 = rmsnorm_bwd(y1, attn_post_ln, dx1) ; do = (T) dy1 ; dx = alpha * dy1      i == 0: do = (T) dx1 ; dx = dx1
@@ -221,7 +227,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     GemmArgs e = {};
     e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = L; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, e, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.ag, dm, lg.out_proj, dm, L, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.ag, dm, lg.out_proj, dm, L, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
     // da = dag*sigmoid(gate) (into g_d) ; dgate -> dqkvg[:, d:2d]
     char* dqkvg = ws.g_nq;
     const size_t es = esz(dt);
@@ -234,7 +240,8 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     GemmArgs q = {};
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, q, s));
-    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, ws.wg_part, ws.wg_part_bytes, s));
+    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_wgrad_flush(&wgb, s));      // the layer's four weight gradients: one summing launch
     // dx += rmsnorm_bwd(X[i], pre_ln, dxn1) = dL/dX[i]; chained with the head of the layer below: through its feed-forward
     // post-norm (layers >= 1) and the bf16 copy df that its w3 products read
     if (i == 0) {
