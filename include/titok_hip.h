@@ -344,6 +344,14 @@ typedef struct ttv_batch {
    * its factors from the L2-resident base table (bit-identical values). */
   const int32_t* rope_ids;
   const float* rope_base;
+  /* optional (NULL / 0: off): an attention work table (format of `qblocks`, full items only) whose entries cover just the query rows of
+   * the LATENT tokens of every sequence (rows [0, K_b): the latent tokens come first, blocks.py:85-86).  The encoder's output is read
+   * from its latent rows alone (blocks.py:101-103), so with this table ttv_encoder_forward runs the LAST layer's attention for those
+   * query rows only (keys / values: every row, as before) and everything behind it - out_proj, KEEL norms, the feed-forward - on the
+   * sum K_b latent rows instead of all L: the same values for the rows that are used, the patch rows of the last layer's output are
+   * never computed.  Ignored by the decoder and by the training entry points. */
+  const int32_t* qblocks_latent;
+  int32_t n_qblocks_latent;
 } ttv_batch;
 
 /* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =

@@ -258,6 +258,37 @@ def test_to_qkv_kernels_agree_inside_the_towers():
         "k_qkv256 and k_qkv256ws share their arithmetic: identical forward expected"
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "split3"])
+def test_encoder_last_layer_on_latent_rows_only_changes_no_bit(mode):
+    """The encoder's output is read from its latent rows (blocks.py:101-103).  With `ttv_batch.qblocks_latent` the last layer runs its
+    attention for the latent query rows only and out_proj / the KEEL norms / the feed-forward on the gathered latent rows; every kernel
+    behind the attention is row-wise and the attention computes a query block by itself, so indices, codes and the pre-rounding latents
+    are the bits of the all-rows forward (ttv_debug_set bit 19 switches the shortcut off).  Mixed shapes: token counts that do and do
+    not fill a 128-row query block, a clip with more tokens than one block."""
+    from titok_video_amd import _lib
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    model = build(dt)
+    if mode == "split3":
+        model.set_index_exact("split3")
+    shapes = [(8, 32, 48), (4, 16, 16), (16, 64, 32), (16, 128, 128), (16, 128, 128)]
+    counts = [5, 1, 17, 128, 200]
+    clips = synthetic_clips(shapes, seed=31, dtype=dt, device=DEV)
+    lib = _lib.lib()
+    outs = []
+    try:
+        for bits in (0, 1 << 19):
+            lib.ttv_debug_set(bits)
+            with torch.no_grad():
+                codes, info = model.encode(clips, counts, want_bounded=True)
+            torch.cuda.synchronize()
+            outs.append((codes.clone(), info["indices"].clone(), model.last_bounded.clone()))
+    finally:
+        lib.ttv_debug_set(0)
+    assert torch.equal(outs[0][1], outs[1][1]), "indices differ"
+    assert torch.equal(outs[0][2], outs[1][2]), "pre-rounding latents differ"
+    assert torch.equal(outs[0][0], outs[1][0]), "codes differ"
+
+
 def test_more_clips_than_one_pointer_table_bf16():
     """Batches of more than TTV_MAX_CLIPS_PER_LAUNCH (64) clips take the stand-alone patch copy / ln_post kernels instead of
     the GEMM-fused gather / scatter: same results up to bf16 rounding of the folded gain."""

@@ -46,6 +46,7 @@ static inline int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 struct TowerWs {
   char *x, *xn, *qkv, *ao, *h, *pa, *pb;
+  char *xl, *aol;    // [sum_tokens, width]: the latent rows of x and of the attention output, compact (encoder, last layer)
   char *f8, *f8mx;   // block-scaled fp8 image of the running linear's input [L, max(width, inner)] and its E8M0 scales
   float* y32;
   float* rstd;     // [L] row statistic of a folded pre-norm (generic-width bf16 towers)
@@ -69,6 +70,8 @@ static TowerWs carve(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
   w.pa = take(P * pd * e);        // encoder: gathered patches; decoder: proj_out output
   w.pb = take(P * d->width * e);  // encoder: proj_in output;   decoder: ln_post output
   w.rstd = (float*)take(L * 4);
+  w.xl = take((int64_t)b->sum_tokens * d->width * e);
+  w.aol = take((int64_t)b->sum_tokens * d->width * e);
   w.f8 = w.f8mx = nullptr;
   if (d->dtype == TTV_BF16 && d->width != 256 && d->width % 128 == 0) {      // the towers that can run the block-scaled fp8 linears
     const int64_t wide = d->width > d->inner ? d->width : d->inner;
@@ -175,6 +178,14 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   bool rstd_valid = false;  // ws.rstd holds rsqrt(mean(x^2) + eps) of the current ws.x (written by the kernel that produced x)
   bool xq_valid = false;    // ws.f8 / ws.f8mx hold the block-scaled e4m3 image of the current ws.x (run_layer_mx)
   static const bool attn_pipe = getenv("TTV_ATTN_PIPE") && getenv("TTV_ATTN_PIPE")[0] == '1';   // opt-in pipelined attention kernel
+  // The encoder's output is its latent rows (blocks.py:101-103): with the batch's latent-query table the LAST layer runs its attention for
+  // those query rows only and everything behind the attention on the sum K_b latent rows, gathered into compact buffers (ws.xl, ws.aol) and
+  // scattered back into ws.x at the end.  Row-wise kernels on other rows: the values of the rows that are read are the same bits.
+  // TTV_ENC_LATENT_LAST=0: every row, as the reference computes it (A/B, tests).  Not for the block-scaled fp8 layers (run_layer_mx).
+  static const bool lat_env = !(getenv("TTV_ENC_LATENT_LAST") && getenv("TTV_ENC_LATENT_LAST")[0] == '0');
+  const bool lat_last = lat_env && !(g_ttv_debug & 524288) && d->kind == TTV_ENCODER && b->qblocks_latent && b->n_qblocks_latent > 0 &&
+                        b->latent_rows && b->sum_tokens > 0 && b->sum_tokens < L;
+  bool compacted = false;
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
     static const bool keel_f32 = getenv("TTV_KEEL_F32SUM") && getenv("TTV_KEEL_F32SUM")[0] == '1';
@@ -221,7 +232,12 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     const bool q_scaled = dt == TTV_BF16 && (lw.to_qkv_pn ? lw.qkv_q_prescaled != 0 : lw.to_qkv_qs != nullptr);
     rstd_valid = false;
     qkv_ready = false;
-    if (q_scaled && b->items64 && b->n_items64 > 0 && d->head_dim == 64)
+    const bool lat_now = lat_last && i == d->layers - 1;
+    if (lat_now)
+      TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks_latent, b->n_qblocks_latent, d->q_heads, d->kv_heads, d->head_dim,
+                             TTV_ATTN_GATE | TTV_ATTN_ALLFULL | (q_scaled ? TTV_ATTN_QSCALED : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
+                                 (s3img ? (TTV_ATTN_SPLIT_OUT | TTV_ATTN_SPLIT_IN) : 0), dt, s));
+    else if (q_scaled && b->items64 && b->n_items64 > 0 && d->head_dim == 64)
       TTV_TRY(ttvk_attention64(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->items64, b->n_items64, d->q_heads, d->kv_heads,
                                TTV_ATTN_GATE | TTV_ATTN_QSCALED, s));
     else
@@ -229,6 +245,17 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
                                (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
                                (s3img ? (TTV_ATTN_SPLIT_OUT | TTV_ATTN_SPLIT_IN) : 0), dt, s));
+    // from here on the layer works on (cx, cao, Lc): the whole packed batch, or - last encoder layer - its latent rows, compact
+    char* cx = ws.x;
+    char* cao = ws.ao;
+    int Lc = L;
+    if (lat_now) {
+      const int64_t rb = (int64_t)dm * esize(dt);       // a split image (hi0..3 | lo0..3 per 16 bytes) has the bytes of the fp32 row
+      TTV_TRY(ttvk_copy_rows(ws.x, (int64_t)dm * esize(dt), b->latent_rows, ws.xl, (int64_t)dm * esize(dt), nullptr, b->sum_tokens, dm * (int)esize(dt), s));
+      TTV_TRY(ttvk_copy_rows(ws.ao, rb, b->latent_rows, ws.aol, rb, nullptr, b->sum_tokens, (int)rb, s));
+      cx = ws.xl; cao = ws.aol; Lc = b->sum_tokens;
+      compacted = true;
+    }
     // TTV_FUSED_MLP=0 selects the unfused kernel sequence (A/B measurements; same results up to bf16 rounding of h).
     // TTV_FUSED_QKV=1 additionally folds the NEXT layer's QKV projection + rotary into the tail kernel: correct and tested,
     // but measured 3 % slower end to end than the stand-alone QKV kernel (the phase runs on the 192 CUs / uneven wave pairs
@@ -242,21 +269,21 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       MlpNextQkv nx = {};
       const bool back = use_fused_qkv && i + 1 < d->layers && lw.mlp_pack_qkv_rows == nq && nq % 64 == 0 && dm % 64 == 0 && g % 64 == 0;
       if (back) { nx.qkv = ws.qkv; nx.ld = nq; nx.rope_cs = b->rope_cs; nx.rows = nq; nx.rope_q_end = dm; nx.rope_k_begin = 2 * dm; nx.rope_k_end = 2 * dm + g; }
-      TTV_TRY(ttvk_mlp_fused(ws.ao, dm, i == 0 ? nullptr : lw.attn_post_ln, i == 0 ? 1.f : d->alpha, ws.x, dm, lw.mlp_pack, d->inner,
-                             ws.x, dm, i == 0 ? nullptr : lw.ffd_post_ln, i == 0 ? 1.f : d->alpha, d->eps, L, back ? &nx : nullptr, s));
+      TTV_TRY(ttvk_mlp_fused(cao, dm, i == 0 ? nullptr : lw.attn_post_ln, i == 0 ? 1.f : d->alpha, cx, dm, lw.mlp_pack, d->inner,
+                             cx, dm, i == 0 ? nullptr : lw.ffd_post_ln, i == 0 ? 1.f : d->alpha, d->eps, Lc, back ? &nx : nullptr, s));
       qkv_ready = back;
       continue;
     }
     GemmArgs o = {};
     o.dtype = dt; o.split3 = split3; o.x_image = s3img;
-    o.x = ws.ao; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = ws.x; o.ldr = dm;
+    o.x = cao; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = Lc; o.N = dm; o.K = dm; o.resid = cx; o.ldr = dm;
     if (i == 0) {
-      o.alpha = 1.f; o.y = ws.x; o.ldy = dm;
+      o.alpha = 1.f; o.y = cx; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
     } else if (ttvk_gemm_supports_resid_norm(dt, dm, dm)) {
       // x <- RMSNorm(alpha*x + ao@Wo^T) * gain in one kernel; in place on x is safe: a token row is read (as residual)
       // and written by the same wave only
-      o.alpha = d->alpha; o.y = ws.x; o.ldy = dm; o.norm_gain = lw.attn_post_ln; o.eps = d->eps;
+      o.alpha = d->alpha; o.y = cx; o.ldy = dm; o.norm_gain = lw.attn_post_ln; o.eps = d->eps;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, o, s));
     } else {
       // wide towers: the KEEL sum alpha * x + f(x) leaves the GEMM through HBM and a row kernel normalises it.  bf16 towers store it
@@ -265,13 +292,13 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       // both kernels.  fp32 towers, and TTV_KEEL_F32SUM=1 (A/B), keep the fp32 buffer.
       const bool want = gen_ok && lw.w12_pn && !f8_w12;
       if (dt == TTV_BF16 && !keel_f32sum) {
-        o.alpha = d->alpha; o.y = ws.x; o.ldy = dm;
+        o.alpha = d->alpha; o.y = cx; o.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
-        TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+        TTV_TRY(ttvk_rmsnorm(cx, dt, dm, nullptr, cx, dt, dm, nullptr, lw.attn_post_ln  , Lc, dm, d->eps, s, want ? ws.rstd : nullptr));
       } else {
         o.alpha = d->alpha; o.y = ws.y32; o.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
-        TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+        TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, cx, dt, dm, nullptr, lw.attn_post_ln  , Lc, dm, d->eps, s, want ? ws.rstd : nullptr));
       }
       rstd_valid = want;
     }
@@ -279,45 +306,47 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     const bool fold_ffd = dt == TTV_BF16 && dm == 256 && lw.w12_pn;
     const bool fold_ffd_gen = gen_ok && lw.w12_pn && !f8_w12;
     if (f8_w12) {
-      TTV_TRY(ttvk_quant_rows_fp8(ws.x, dt, dm, lw.ffd_norm, d->eps, ws.xn, dm, f8_scales, L, dm, s));
+      TTV_TRY(ttvk_quant_rows_fp8(cx, dt, dm, lw.ffd_norm, d->eps, ws.xn, dm, f8_scales, Lc, dm, s));
       GemmArgs f = {};
-      f.dtype = dt; f.x = ws.xn; f.ldx = dm; f.w = lw.w12_f8; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
+      f.dtype = dt; f.x = ws.xn; f.ldx = dm; f.w = lw.w12_f8; f.ldw = dm; f.M = Lc; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
       TTV_TRY(ttvk_gemm_fp8(EPI_GEGLU, f, f8_scales, lw.w12_f8_scale, s));
     } else {
-    if (fold_ffd_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(ws.x, dt, dm, ws.rstd, L, dm, d->eps, s));
-    if (!fold_ffd && !fold_ffd_gen) TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s, nullptr, nullptr, nullptr, s3img));
+    if (fold_ffd_gen && !rstd_valid) TTV_TRY(ttvk_row_rstd(cx, dt, dm, ws.rstd  , Lc, dm, d->eps, s));
+    if (!fold_ffd && !fold_ffd_gen) TTV_TRY(ttvk_rmsnorm(cx, dt, dm, nullptr, ws.xn, dt, dm, nullptr, lw.ffd_norm  , Lc, dm, d->eps, s, nullptr, nullptr, nullptr, s3img));
     GemmArgs f = {};
     f.dtype = dt; f.split3 = split3; f.x_image = s3img && !fold_ffd && !fold_ffd_gen; f.y_image = s3img;
     f.prenorm = fold_ffd; f.eps = d->eps;
     f.row_scale = fold_ffd_gen ? ws.rstd : nullptr;
-    f.x = (fold_ffd || fold_ffd_gen) ? ws.x : ws.xn; f.ldx = dm; f.w = (fold_ffd || fold_ffd_gen) ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = L; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
+    f.x = (fold_ffd || fold_ffd_gen) ? cx : ws.xn; f.ldx = dm; f.w = (fold_ffd || fold_ffd_gen) ? lw.w12_pn : lw.w12; f.ldw = dm; f.M = Lc; f.N = d->inner; f.K = dm; f.y = ws.h; f.ldy = d->inner;
     TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
     }
     rstd_valid = false;
     GemmArgs f3 = {};
     f3.dtype = dt; f3.split3 = split3; f3.x_image = s3img;
-    f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = L; f3.N = dm; f3.K = d->inner; f3.resid = ws.x; f3.ldr = dm;
+    f3.x = ws.h; f3.ldx = d->inner; f3.w = lw.w3; f3.ldw = d->inner; f3.M = Lc; f3.N = dm; f3.K = d->inner; f3.resid = cx; f3.ldr = dm;
     if (i == 0) {
-      f3.alpha = 1.f; f3.y = ws.x; f3.ldy = dm;
+      f3.alpha = 1.f; f3.y = cx; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
     } else if (ttvk_gemm_supports_resid_norm(dt, dm, d->inner)) {
       // x <- RMSNorm(alpha*x + h@W3^T) * gain in one full-row kernel (in place: a token row is read and written by one block)
-      f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
+      f3.alpha = d->alpha; f3.y = cx; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
       const bool want = gen_ok && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn && !(w->layers[i + 1].to_qkv_f8 && w->layers[i + 1].to_qkv_f8_scale);
       if (dt == TTV_BF16 && !keel_f32sum) {      // see the attention sub-layer above
-        f3.alpha = d->alpha; f3.y = ws.x; f3.ldy = dm;
+        f3.alpha = d->alpha; f3.y = cx; f3.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
-        TTV_TRY(ttvk_rmsnorm(ws.x, dt, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+        TTV_TRY(ttvk_rmsnorm(cx, dt, dm, nullptr, cx, dt, dm, nullptr, lw.ffd_post_ln  , Lc, dm, d->eps, s, want ? ws.rstd : nullptr));
       } else {
         f3.alpha = d->alpha; f3.y = ws.y32; f3.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
-        TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, ws.x, dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s, want ? ws.rstd : nullptr));
+        TTV_TRY(ttvk_rmsnorm(ws.y32, TTV_F32, dm, nullptr, cx, dt, dm, nullptr, lw.ffd_post_ln  , Lc, dm, d->eps, s, want ? ws.rstd : nullptr));
       }
       rstd_valid = want;
     }
   }
+  if (compacted)     // the latent rows back where the encoder's tail (and anybody else) reads them
+    TTV_TRY(ttvk_copy_rows(ws.xl, (int64_t)dm * esize(dt), nullptr, ws.x, (int64_t)dm * esize(dt), b->latent_rows, b->sum_tokens, dm * (int)esize(dt), s));
   return TTV_OK;
 }
 

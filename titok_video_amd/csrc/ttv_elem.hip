@@ -114,6 +114,29 @@ __global__ __launch_bounds__(256) void k_row_rstd(const T* __restrict__ in, int 
   if (lane == 0) rstd[r] = 1.0f / sqrtf(ss / (float)d + eps);
 }
 
+// rows gathered / scattered through optional row maps, 16 bytes per thread and step (the encoder's last layer: latent rows -> compact)
+__global__ __launch_bounds__(256) void k_copy_rows(const char* __restrict__ src, long ld_src, const int* __restrict__ src_rows, char* __restrict__ dst,
+                                                   long ld_dst, const int* __restrict__ dst_rows, int rows, int chunks) {
+  const long total = (long)rows * chunks;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / chunks), c = (int)(i % chunks);
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (long)(src_rows ? src_rows[r] : r) * ld_src + c * 16);
+    *reinterpret_cast<uint4*>(dst + (long)(dst_rows ? dst_rows[r] : r) * ld_dst + c * 16) = v;
+  }
+}
+int ttvk_copy_rows(const void* src, int64_t ld_src_bytes, const int* src_rows, void* dst, int64_t ld_dst_bytes, const int* dst_rows, int rows,
+                   int row_bytes, hipStream_t s) {
+  if (rows == 0 || row_bytes == 0) return TTV_OK;
+  TTV_CHECK_ARG(src && dst && row_bytes % 16 == 0 && ld_src_bytes % 16 == 0 && ld_dst_bytes % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0,
+                "copy_rows: 16-byte rows");
+  const long total = (long)rows * (row_bytes / 16);
+  int blocks = (int)((total + 255) / 256);
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, (const char*)src, (long)ld_src_bytes, src_rows, (char*)dst, (long)ld_dst_bytes, dst_rows, rows, row_bytes / 16);
+  TTV_CHECK_LAUNCH("copy_rows");
+  return TTV_OK;
+}
+
 int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, int d, float eps, hipStream_t s) {
   if (rows == 0) return TTV_OK;
   TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS && ld_in % 4 == 0, "row_rstd: width / leading dim");

@@ -11,6 +11,9 @@ int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, v
                  void* mx_q = nullptr, void* mx_s = nullptr,    // mx_q / mx_s: the stored row also as block-scaled e4m3 [rows, d] + its E8M0 scales
                  int split_image = 0);                          // fp32 output written as the split-bf16 image (hi0..3 | lo0..3 per four elements)
 int ttvk_row_rstd(const void* in, int dtype, int ld_in, float* rstd, int rows, int d, float eps, hipStream_t s);
+// dst[dst_rows ? dst_rows[r] : r] = src[src_rows ? src_rows[r] : r] for r < rows; row_bytes a multiple of 16, rows 16-byte aligned
+int ttvk_copy_rows(const void* src, int64_t ld_src_bytes, const int* src_rows, void* dst, int64_t ld_dst_bytes, const int* dst_rows, int rows,
+                   int row_bytes, hipStream_t s);
 int ttvk_fill_const_rows(void* x, int dtype, int ld, const int* rows_map, int rows, int d, const float* mask_token,
                          const float* gain, float eps, hipStream_t s);
 int ttvk_dec_embed(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain,

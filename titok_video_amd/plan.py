@@ -296,6 +296,37 @@ class BatchPlan:
             self._attn_all_full[t.data_ptr()] = not bool((flat[:last, 3] > 0).any())
         return t
 
+    def attention_table_latent(self, q_heads: int, kv_heads: int) -> torch.Tensor:
+        """int32 [n,4] attention work table like `attention_table`, restricted to the query blocks that hold LATENT tokens (rows
+        [0, K_b) of every sequence; full items only).  The encoder reads its output from the latent rows alone (reference
+        blocks.py:101-103), so its last layer needs attention outputs for these query rows only (`ttv_batch.qblocks_latent`): at the
+        benchmark shape 128 entries instead of 1152.  Same XCD interleaving as the full table (a (sequence, kv-head) unit keeps one list)."""
+        key = ("latent", int(q_heads), int(kv_heads))
+        t = self._attn.get(key)
+        if t is None:
+            rep = q_heads // kv_heads
+            units = []
+            for b in range(len(self.grids)):
+                nq = -(-int(self.token_counts[b]) // QBLOCK)
+                for kvh in range(kv_heads):
+                    units.append([(b, qb * QBLOCK, kvh * rep + r, 0) for qb in range(nq) for r in range(rep)])
+            order = sorted(range(len(units)), key=lambda i: len(units[i]), reverse=True)
+            lists, weight = [[] for _ in range(8)], [0] * 8
+            for i in order:
+                x = min(range(8), key=lambda j: weight[j])
+                lists[x].extend(units[i])
+                weight[x] += len(units[i])
+            depth = max(len(l) for l in lists)
+            table = np.full((depth, 8, 4), -1, dtype=np.int32)
+            for x, l in enumerate(lists):
+                if l:
+                    table[: len(l), x, :] = np.asarray(l, dtype=np.int32)
+            flat = table.reshape(-1, 4)
+            last = int(np.max(np.nonzero(flat[:, 0] >= 0)[0])) + 1
+            t = _upload(np.ascontiguousarray(flat[:last]), self.device)
+            self._attn[key] = t
+        return t
+
     def attention_table64(self, q_heads: int, kv_heads: int) -> torch.Tensor:
         """int32 [n,8] work table of ttv_attention64 (the 64-query-rows-per-wave kernel): one entry per workgroup =
         (sequence, kv-head, 4 x wave item, first packed row of the sequence, its length); a wave item is
@@ -350,8 +381,11 @@ class BatchPlan:
         # are 18 % of its life and 576 workgroups on 512 resident slots leave a tail: 77-80 us against 60-62 us at the benchmark
         # batch; at S = 9216 both kernels reach the same 0.37 of the MFMA peak (1 119 vs 1 120 us).
         t64 = self.attention_table64(q_heads, kv_heads) if (q_heads <= 255 and os.environ.get("TTV_ATTN64", "0") == "1") else None
+        # the encoder's last layer on its latent rows only (ttv_batch.qblocks_latent; TTV_ENC_LATENT_LAST=0 in the library: A/B)
+        tl = self.attention_table_latent(q_heads, kv_heads) if sum(int(k) for k in self.token_counts) > 0 else None
         return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
                           items64=t64.data_ptr() if t64 is not None else None, n_items64=int(t64.shape[0]) if t64 is not None else 0,
+                          qblocks_latent=tl.data_ptr() if tl is not None else None, n_qblocks_latent=int(tl.shape[0]) if tl is not None else 0,
                           **self._base_fields)
 
     # views used by tests that call single ops
