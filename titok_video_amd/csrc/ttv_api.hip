@@ -190,7 +190,8 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     const ttv_layer_weights& lw = w->layers[i];
     static const bool keel_f32 = getenv("TTV_KEEL_F32SUM") && getenv("TTV_KEEL_F32SUM")[0] == '1';
     if (dt == TTV_BF16 && dm != 256 && dm % 128 == 0 && d->inner % 128 == 0 && !keel_f32 && lw.to_qkv_f8 && lw.to_qkv_mx && lw.w12_f8 && lw.w12_mx &&
-        lw.out_proj_f8 && lw.out_proj_mx && lw.w3_f8 && lw.w3_mx) {
+        lw.out_proj_f8 && lw.out_proj_mx && lw.w3_f8 && lw.w3_mx &&
+        !(lat_last && i == d->layers - 1)) {    // the encoder's last layer: its latent rows on the bf16 kernels instead (a ninth of the rows)
       TTV_TRY(run_layer_mx(d, lw, b, ws, i, rstd_valid, xq_valid, attn_pipe, s));
       qkv_ready = false;
       continue;
