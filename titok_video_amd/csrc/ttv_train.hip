@@ -25,6 +25,7 @@ struct Tape {
   char *patches, *pe, *hpre, *pn;     // encoder: gathered patches, proj_in output (pre-norm); decoder: pre-norm latent rows, ln_post out
   char* X[65];                        // residual stream at every layer boundary (X[0] = tower input rows, X[layers] = output)
   struct L { char *xn1, *qkvg, *a, *ag, *x1, *xn2, *u, *h; float *lse, *y1, *y2; } l[64];
+  char *agc, *xc;                     // encoder, last layer: its latent rows of ag and of X[layers - 1], compact (see latent_tail)
 };
 
 static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
@@ -36,7 +37,8 @@ static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
   auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
   t.base = base;
   t.patches = t.pe = t.hpre = t.pn = nullptr;
-  if (d->kind == TTV_ENCODER) { t.patches = take(P * pd * e); t.pe = take(P * dm * e); }
+  t.agc = t.xc = nullptr;
+  if (d->kind == TTV_ENCODER) { t.patches = take(P * pd * e); t.pe = take(P * dm * e); t.agc = take(K * dm * e); t.xc = take(K * dm * e); }
   else { t.hpre = take(K * dm * e); t.pn = take(P * dm * e); }
   for (int i = 0; i <= d->layers; ++i) t.X[i] = take(L * dm * e);
   for (int i = 0; i < d->layers; ++i) {
@@ -52,6 +54,7 @@ static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
 
 struct BwdWs {
   float *dxa, *dxb, *delta, *dkv, *colsum, *small_f32;
+  float* dxc;       // [sum_tokens, width] fp32: the latent rows of the residual-stream gradient, compact (encoder, last layer)
   char *g_d, *g_d2, *g_i, *g_2i, *g_nq, *g_pd;
   float* wg_part;
   int64_t wg_part_bytes;
@@ -69,6 +72,7 @@ static BwdWs carve_bwd(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
   w.dkv = (float*)take(d->dtype == TTV_F32 ? L * 2 * g * 4 : 0);
   w.colsum = (float*)take(dm * 4);
   w.small_f32 = (float*)take(L * dm * 4);          // fp32 [rows, d] scratch for the d <-> token_size projections
+  w.dxc = (float*)take((int64_t)b->sum_tokens * dm * 4);
   w.g_d = take(L * dm * e); w.g_d2 = take(L * dm * e); w.g_i = take(L * d->inner * e); w.g_2i = take(L * 2 * d->inner * e);
   w.g_nq = take(L * nq * e); w.g_pd = take(P * pd * e);
   // split partial tiles of the weight-gradient GEMMs (largest of the shapes the tower uses)
@@ -100,6 +104,17 @@ static int check(const ttv_tower_dims* d, const ttv_batch* b) {
   return TTV_OK;
 }
 
+// The encoder's output is read from its latent rows only (blocks.py:101-103): in its LAST layer everything behind the attention - out_proj,
+// the KEEL norms, the feed-forward - runs on the sum K_b latent rows, gathered into compact buffers; the tape entries of that sub-layer
+// (x1, xn2, u, h, y1, y2) then hold those rows in their first sum K_b rows, and the backward gathers / scatters accordingly.  The gradient
+// of the loss with respect to the last layer's patch-row outputs is zero, so nothing is lost; attention (forward and backward) still runs
+// on every row - a query row with dO = 0 contributes nothing.  TTV_ENC_LATENT_LAST=0 / ttv_debug_set bit 19: every row (A/B, tests).
+static bool latent_tail(const ttv_tower_dims* d, const ttv_batch* b, int layer) {
+  static const bool env = !(getenv("TTV_ENC_LATENT_LAST") && getenv("TTV_ENC_LATENT_LAST")[0] == '0');
+  return env && !(g_ttv_debug & 524288) && d->kind == TTV_ENCODER && layer == d->layers - 1 && b->latent_rows && b->sum_tokens > 0 &&
+         b->sum_tokens < b->total_rows && d->inner >= d->width;
+}
+
 // ------------------------------------------------------------------------------------------------ forward (tape)
 static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, Tape& t, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
@@ -129,8 +144,19 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
                              b->qblocks_paired ? TTV_ATTN_PAIRED : 0, dt, s, l.lse));
       TTV_TRY(ttvk_gate_fwd(l.a, dm, (const char*)l.qkvg + (size_t)dm * esz(dt), nq, l.ag, dm, L, dm, dt, s));
     }
+    // the rest of the layer on (Lc rows: ag_in, x_in): every row, or - encoder, last layer - the latent rows, compact
+    const bool lat = latent_tail(d, b, i);
+    const int Lc = lat ? b->sum_tokens : L;
+    char* ag_in = l.ag;
+    char* x_in = t.X[i];
+    char* x_out = t.X[i + 1];
+    if (lat) {
+      TTV_TRY(ttvk_copy_rows(l.ag, (int64_t)dm * esz(dt), b->latent_rows, t.agc, (int64_t)dm * esz(dt), nullptr, Lc, dm * esz(dt), s));
+      TTV_TRY(ttvk_copy_rows(t.X[i], (int64_t)dm * esz(dt), b->latent_rows, t.xc, (int64_t)dm * esz(dt), nullptr, Lc, dm * esz(dt), s));
+      ag_in = t.agc; x_in = t.xc; x_out = t.xc;          // the layer's output: compact in place of its input rows, scattered below
+    }
     GemmArgs o = {};
-    o.dtype = dt; o.x = l.ag; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = L; o.N = dm; o.K = dm; o.resid = t.X[i]; o.ldr = dm;
+    o.dtype = dt; o.x = ag_in; o.ldx = dm; o.w = lw.out_proj; o.ldw = dm; o.M = Lc; o.N = dm; o.K = dm; o.resid = x_in; o.ldr = dm;
     if (i == 0) {
       o.alpha = 1.f; o.y = l.x1; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
@@ -141,28 +167,28 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     } else {
       o.alpha = d->alpha; o.y = l.y1; o.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
-      TTV_TRY(ttvk_rmsnorm(l.y1, TTV_F32, dm, nullptr, l.x1, dt, dm, nullptr, lw.attn_post_ln, L, dm, d->eps, s));
+      TTV_TRY(ttvk_rmsnorm(l.y1, TTV_F32, dm, nullptr, l.x1, dt, dm, nullptr, lw.attn_post_ln, Lc, dm, d->eps, s));
     }
     if (!(i > 0 && fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, dm)))
-      TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, L, dm, d->eps, s));
+      TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, Lc, dm, d->eps, s));
     GemmArgs f = {};
     if (dt == TTV_BF16) {
       // one launch: u = xn2 W12^T kept for the backward (through `resid`) and h = gelu(gate) * x from the stored values
-      f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = I; f.K = dm; f.y = l.h; f.ldy = I;
+      f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = Lc; f.N = I; f.K = dm; f.y = l.h; f.ldy = I;
       f.resid = l.u; f.ldr = 2 * I;
       TTV_TRY(ttvk_gemm(EPI_GEGLU, f, s));
     } else {
-      f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = L; f.N = 2 * I; f.K = dm; f.y = l.u; f.ldy = 2 * I;
+      f.dtype = dt; f.x = l.xn2; f.ldx = dm; f.w = lw.w12; f.ldw = dm; f.M = Lc; f.N = 2 * I; f.K = dm; f.y = l.u; f.ldy = 2 * I;
       TTV_TRY(ttvk_gemm(EPI_STORE, f, s));
-      TTV_TRY(ttvk_geglu_fwd(l.u, 2 * I, l.h, I, L, I, dt, s));
+      TTV_TRY(ttvk_geglu_fwd(l.u, 2 * I, l.h, I, Lc, I, dt, s));
     }
     GemmArgs f3 = {};
-    f3.dtype = dt; f3.x = l.h; f3.ldx = I; f3.w = lw.w3; f3.ldw = I; f3.M = L; f3.N = dm; f3.K = I; f3.resid = l.x1; f3.ldr = dm;
+    f3.dtype = dt; f3.x = l.h; f3.ldx = I; f3.w = lw.w3; f3.ldw = I; f3.M = Lc; f3.N = dm; f3.K = I; f3.resid = l.x1; f3.ldr = dm;
     if (i == 0) {
-      f3.alpha = 1.f; f3.y = t.X[i + 1]; f3.ldy = dm;
+      f3.alpha = 1.f; f3.y = x_out; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
     } else if (fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, I)) {
-      f3.alpha = d->alpha; f3.y = t.X[i + 1]; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
+      f3.alpha = d->alpha; f3.y = x_out; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
       f3.sum_f32 = l.y2; f3.ld_sum = dm;
       if (i + 1 < d->layers) {          // the next layer's pre-norm rides along
         f3.y2 = t.l[i + 1].xn1; f3.ldy2 = dm; f3.norm_gain2 = w->layers[i + 1].pre_ln;
@@ -172,8 +198,10 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     } else {
       f3.alpha = d->alpha; f3.y = l.y2; f3.ldy = dm;
       TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
-      TTV_TRY(ttvk_rmsnorm(l.y2, TTV_F32, dm, nullptr, t.X[i + 1], dt, dm, nullptr, lw.ffd_post_ln, L, dm, d->eps, s));
+      TTV_TRY(ttvk_rmsnorm(l.y2, TTV_F32, dm, nullptr, x_out, dt, dm, nullptr, lw.ffd_post_ln, Lc, dm, d->eps, s));
     }
+    if (lat)     // the latent rows of the tower's output where the tail (and the backward) read them; its patch rows are never read
+      TTV_TRY(ttvk_copy_rows(t.xc, (int64_t)dm * esz(dt), nullptr, t.X[i + 1], (int64_t)dm * esz(dt), b->latent_rows, Lc, dm * esz(dt), s));
   }
   return TTV_OK;
 }
@@ -195,43 +223,64 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     // ---------------- feed-forward sub-layer: X[i+1] = post_ln(alpha*x1 + w3 h)  (layer 0: x1 + w3 h) ----------------
     // The top layer undoes its feed-forward post-norm here; for the layers below it was chained onto the pre_ln backward of the
     // layer above (end of the previous iteration).
+    // encoder, last layer: the sub-layers behind the attention ran on the latent rows only (latent_tail): their backward does too, on the
+    // gathered latent rows of dL/dX[layers] (every other row of it is zero)
+    const bool lat = latent_tail(d, b, i);
+    const int Lc = lat ? b->sum_tokens : L;
+    const long nLc = (long)Lc * dm;
+    float* const dxf = dx;                 // the full-size gradient buffer
+    if (lat) {
+      TTV_TRY(ttvk_copy_rows(dxf, (int64_t)dm * 4, b->latent_rows, ws.dxc, (int64_t)dm * 4, nullptr, Lc, dm * 4, s));
+      dx = ws.dxc;
+    }
     float* dx1;
     if (i == d->layers - 1) {
       if (i > 0) {
-        TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, L, dm, d->eps, s));
+        TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, Lc, dm, d->eps, s));
         // tmp = dy2 ; df (T) = dy2 ; dx1 = alpha * dy2 (into dx)
-        TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLd, s));
+        TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLc, s));
       } else {
-        TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, ws.g_d, dt, nLd, s));   // df = (T) dx ; dx1 = dx
+        TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, ws.g_d, dt, nLc, s));   // df = (T) dx ; dx1 = dx
       }
     }
     dx1 = dx;
     // dh = df W3 ; dW3 += df^T h
     GemmArgs a = {};
-    a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = L; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
+    a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = Lc; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
     TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, L, dm, I, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
-    TTV_TRY(ttvk_geglu_bwd(l.u, 2 * I, ws.g_i, I, ws.g_2i, 2 * I, L, I, dt, s));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, Lc, dm, I, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_geglu_bwd(l.u, 2 * I, ws.g_i, I, ws.g_2i, 2 * I, Lc, I, dt, s));
     // dxn2 = du W12 ; dW12 += du^T xn2
     GemmArgs c = {};
-    c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = L; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
+    c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = Lc; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, c, s));
-    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, L, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, Lc, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
     // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2), then straight through the attention sub-layer's post-norm:
     // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
     // i > 0: dy1 = rmsnorm_bwd(y1, attn_post_ln, dx1) ; do = (T) dy1 ; dx = alpha * dy1      i == 0: do = (T) dx1 ; dx = dx1
     TTV_TRY(ttvk_rmsnorm_bwd_chain(l.x1, dm, ws.g_d2, dm, lw.ffd_norm, lg.ffd_norm, dx1, dm, i > 0 ? l.y1 : nullptr, dm,
-                                   i > 0 ? lw.attn_post_ln : nullptr, i > 0 ? lg.attn_post_ln : nullptr, i > 0 ? d->alpha : 1.f, ws.g_d, dm, L,
+                                   i > 0 ? lw.attn_post_ln : nullptr, i > 0 ? lg.attn_post_ln : nullptr, i > 0 ? d->alpha : 1.f, ws.g_d, dm, Lc,
                                    dm, d->eps, dt, s));
     // dag = do Wo ; dWo += do^T ag
     GemmArgs e = {};
-    e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = L; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
+    e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = Lc; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, e, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.ag, dm, lg.out_proj, dm, L, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_wgrad(ws.g_d, dm, lat ? t.agc : l.ag, dm, lg.out_proj, dm, Lc, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    // back to every row: the gradient of the attention output and of the residual stream are zero outside the latent rows
+    char* dag = ws.g_d2;
+    if (lat) {
+      const size_t es_ = esz(dt);
+      (void)hipMemsetAsync(ws.g_i, 0, (size_t)L * dm * es_, s);
+      TTV_TRY(ttvk_copy_rows(ws.g_d2, (int64_t)dm * es_, nullptr, ws.g_i, (int64_t)dm * es_, b->latent_rows, Lc, dm * (int)es_, s));
+      dag = ws.g_i;
+      (void)hipMemsetAsync(dxf, 0, (size_t)L * dm * sizeof(float), s);
+      TTV_TRY(ttvk_copy_rows(ws.dxc, (int64_t)dm * 4, nullptr, dxf, (int64_t)dm * 4, b->latent_rows, Lc, dm * 4, s));
+      dx = dxf;
+    }
     // da = dag*sigmoid(gate) (into g_d) ; dgate -> dqkvg[:, d:2d]
     char* dqkvg = ws.g_nq;
     const size_t es = esz(dt);
-    TTV_TRY(ttvk_gate_bwd(ws.g_d2, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt,
+    TTV_TRY(ttvk_gate_bwd(dag, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt,
                           ws.delta, s));   // also fills delta = sum_d da * a per (row, head) for the attention backward
     // attention backward -> dq, dk, dv columns of dqkvg
     TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, ws.g_d, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
