@@ -1163,13 +1163,24 @@ __global__ __launch_bounds__(256) void k_attn_delta(const T* __restrict__ dout, 
   delta[i] = acc;
 }
 
+// Query rows of a sequence that take part in the attention backward.  qlim_desc = the batch's clip descriptors (entries 3-5 of a clip: its
+// patch grid; the latent tokens are the K_b = S - gt * gh * gw rows in front of the patches) when the forward computed the attention of the LATENT query rows only (encoder,
+// last layer: ttv_train.hip latent_tail) - whole 128-row query blocks, as the forward's work table; the rows behind have dO = 0 and no
+// valid log-sum-exp, they are skipped (dQ = 0, no contribution to dK / dV).  NULL: every row.
+__device__ __forceinline__ int attn_bwd_query_rows(const int* __restrict__ qlim_desc, int seq, int s0, int S) {
+  if (!qlim_desc) return S;
+  const int kb = S - qlim_desc[8 * seq + 3] * qlim_desc[8 * seq + 4] * qlim_desc[8 * seq + 5];     // latent tokens = rows - patches (gt * gh * gw)
+  const int lim = (kb + 127) / 128 * 128;
+  return lim < S ? lim : S;
+}
+
 // naive fp32 backward: one wave per (query row, q-head); lane = head dim.  dk/dv accumulate with fp32 atomics into
 // [L, g] scratch (zeroed by the caller), dq is written directly.
 __global__ __launch_bounds__(256) void k_attn_bwd_f32(const float* __restrict__ qkvg, int ld, const float* __restrict__ dout, int ldd,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       const int* __restrict__ cu, const int* __restrict__ row_seq,
                                                       float* __restrict__ dqkvg, int ldg, float* __restrict__ dkv, int total_rows,
-                                                      int hq, int hkv, float scale) {
+                                                      int hq, int hkv, float scale, const int* __restrict__ qlim_desc) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + wave;
   if (idx >= total_rows * hq) return;
@@ -1177,6 +1188,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_f32(const float* __restrict__ 
   const int d_model = hq * 64, gqa = hkv * 64, kvh = h / (hq / hkv);
   const int seq = row_seq[t];
   const int s0 = cu[seq], s1 = cu[seq + 1];
+  if (qlim_desc && t - s0 >= attn_bwd_query_rows(qlim_desc, seq, s0, s1 - s0)) {   // a query row the forward did not compute: no gradient
+    dqkvg[(size_t)t * ldg + h * 64 + lane] = 0.f;
+    return;
+  }
   const float q = qkvg[(size_t)t * ld + h * 64 + lane];
   const float dov = dout[(size_t)t * ldd + h * 64 + lane];
   const float l = lse[(size_t)t * hq + h], dl = delta[(size_t)t * hq + h];
@@ -1272,7 +1287,7 @@ __device__ __forceinline__ void attn_bwd_dkv_block(uint4* tiles, float (*ls)[2][
                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                    const int* __restrict__ cu, const int* __restrict__ blocks,
                                                    bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale,
-                                                   const float* __restrict__ rope_cs) {
+                                                   const float* __restrict__ rope_cs, const int* __restrict__ qlim_desc) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
@@ -1285,7 +1300,7 @@ __device__ __forceinline__ void attn_bwd_dkv_block(uint4* tiles, float (*ls)[2][
   const bf16_t* dbase = dout + (size_t)s0 * ldd;
   const uint32_t tiles_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&tiles[0];
   const uint32_t ls_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&ls[0][0][0];
-  const int nqb = (S + 63) / 64, nsteps = rep * nqb;
+  const int nqb = (attn_bwd_query_rows(qlim_desc, seq, s0, S) + 63) / 64, nsteps = rep * nqb;      // query blocks that carry a gradient
 #define DKV_ISSUE(step_, buf_)                                                                              \
   do {                                                                                                      \
     const int hr__ = (step_) / nqb, q0__ = ((step_) - hr__ * nqb) * 64, h__ = kvh * rep + hr__;             \
@@ -1423,7 +1438,7 @@ __device__ __forceinline__ void attn_bwd_dq_block(uint4* tiles, const int bx, co
                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                   const int* __restrict__ cu, const int* __restrict__ blocks,
                                                   bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale,
-                                                  const float* __restrict__ rope_cs) {
+                                                  const float* __restrict__ rope_cs, const int* __restrict__ qlim_desc) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
@@ -1431,6 +1446,16 @@ __device__ __forceinline__ void attn_bwd_dq_block(uint4* tiles, const int bx, co
   const int seq = blocks[2 * bx], q0 = blocks[2 * bx + 1];
   const int h = by;
   const int s0 = cu[seq], S = cu[seq + 1] - s0;
+  if (qlim_desc && q0 >= attn_bwd_query_rows(qlim_desc, seq, s0, S)) {     // query rows without a gradient: dQ = 0 (block-uniform)
+    const int row = q0 + (tid >> 2), c0 = (tid & 3) * 16;                     // 64 rows x 64 columns, 16 columns per thread
+    if (row < S) {
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      uint4* dst = reinterpret_cast<uint4*>(dqkvg + (size_t)(s0 + row) * ldg + h * 64 + c0);
+      dst[0] = z;
+      dst[1] = z;
+    }
+    return;
+  }
   const int d_model = hq * 64, gqa = hkv * 64, kvh = h / (hq / hkv);
   const bf16_t* base = qkvg + (size_t)s0 * ld;
   const bf16_t* kbase = base + 2 * d_model + kvh * 64;
@@ -1546,16 +1571,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(const bf16_t* __restrict__ 
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      const int* __restrict__ cu, const int* __restrict__ blocks, int n_blocks,
                                                      bf16_t* __restrict__ dqkvg, int ldg, int hq, int hkv, float scale,
-                                                     const float* __restrict__ rope_cs) {
+                                                     const float* __restrict__ rope_cs, const int* __restrict__ qlim_desc) {
   __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512];
   __shared__ __attribute__((aligned(16))) float ls[2][2][64];
   const int n_dkv = n_blocks * hkv;
   int b = blockIdx.x;
   if (b < n_dkv) {
-    attn_bwd_dkv_block(tiles, ls, b % n_blocks, b / n_blocks, qkvg, ld, dout, ldd, lse, delta, cu, blocks, dqkvg, ldg, hq, hkv, scale, rope_cs);
+    attn_bwd_dkv_block(tiles, ls, b % n_blocks, b / n_blocks, qkvg, ld, dout, ldd, lse, delta, cu, blocks, dqkvg, ldg, hq, hkv, scale, rope_cs, qlim_desc);
   } else {
     b -= n_dkv;
-    attn_bwd_dq_block(tiles, b % n_blocks, b / n_blocks, qkvg, ld, dout, ldd, lse, delta, cu, blocks, dqkvg, ldg, hq, hkv, scale, rope_cs);
+    attn_bwd_dq_block(tiles, b % n_blocks, b / n_blocks, qkvg, ld, dout, ldd, lse, delta, cu, blocks, dqkvg, ldg, hq, hkv, scale, rope_cs, qlim_desc);
   }
 }
 
@@ -1563,7 +1588,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(const bf16_t* __restrict__ 
 // (fp32 path); dkv_scratch: fp32 [L, 2g] zeroed by this function (fp32 path only).
 int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                        const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
-                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s, int delta_ready) {
+                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s, int delta_ready, const int* qlim_desc) {
   if (total_rows == 0) return TTV_OK;
   const float scale = 0.125f;
   const int d_model = hq * 64, gqa = hkv * 64;
@@ -1574,12 +1599,12 @@ int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const v
   TTV_CHECK_LAUNCH("attn_delta");
   if (dt == TTV_BF16) {
     hipLaunchKernelGGL(k_attn_bwd, dim3(n_blocks64 * (hkv + hq)), dim3(256), 0, s, (const bf16_t*)qkvg, ld, (const bf16_t*)dout, ldd, lse, delta, cu,
-                       blocks64, n_blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs);
+                       blocks64, n_blocks64, (bf16_t*)dqkvg, ldg, hq, hkv, scale, rope_cs, qlim_desc);
     TTV_CHECK_LAUNCH("attn_bwd");
   } else {
     TTV_CHECK_ARG(dkv_scratch && row_seq, "attention_bwd: fp32 path needs scratch and row map");
     (void)hipMemsetAsync(dkv_scratch, 0, (size_t)total_rows * 2 * gqa * sizeof(float), s);
-    hipLaunchKernelGGL(k_attn_bwd_f32, dim3(ttv_cdiv(total_rows * hq, 4)), dim3(256), 0, s, (const float*)qkvg, ld, (const float*)dout, ldd, lse, delta, cu, row_seq, (float*)dqkvg, ldg, dkv_scratch, total_rows, hq, hkv, scale);
+    hipLaunchKernelGGL(k_attn_bwd_f32, dim3(ttv_cdiv(total_rows * hq, 4)), dim3(256), 0, s, (const float*)qkvg, ld, (const float*)dout, ldd, lse, delta, cu, row_seq, (float*)dqkvg, ldg, dkv_scratch, total_rows, hq, hkv, scale, qlim_desc);
     TTV_CHECK_LAUNCH("attn_bwd_f32");
     // copy dk|dv scratch [L, 2g] into the k, v columns of dqkvg
     (void)hipMemcpy2DAsync((float*)dqkvg + 2 * d_model, (size_t)ldg * sizeof(float), dkv_scratch, (size_t)2 * gqa * sizeof(float),

@@ -177,7 +177,7 @@ int ttvk_reduce_small(const void* a, int a_dt, int lda, const int* a_rows, const
                       int rows, int d, hipStream_t s);
 int ttvk_attention_bwd(const void* qkvg, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse, float* delta,
                        const int* cu, const int* blocks64, int n_blocks64, const int* row_seq, void* dqkvg, int ldg, float* dkv_scratch,
-                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s, int delta_ready = 0);
+                       int total_rows, int hq, int hkv, int dt, const float* rope_cs, hipStream_t s, int delta_ready = 0, const int* qlim_desc = nullptr);
 int ttvk_rope_apply_dir(void* x, int dtype, int ld, int rows, int heads, const float* cs, int conj, hipStream_t s);
 int ttvk_dec_embed_ex(const void* codes, int C, const void* w, const void* bias, const float* mask_token, const float* gain, void* x,
                       int dtype, int ld, const int* rows_map, int rows, int d, float eps, void* hpre, hipStream_t s);

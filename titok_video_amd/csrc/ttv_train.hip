@@ -115,6 +115,12 @@ static bool latent_tail(const ttv_tower_dims* d, const ttv_batch* b, int layer) 
          b->sum_tokens < b->total_rows && d->inner >= d->width;
 }
 
+// ... and the attention itself for the latent QUERY rows only (keys / values: every row), forward and backward, when the batch carries the
+// latent work table and the clip descriptors (the backward derives K_b from them)
+static bool latent_attn(const ttv_tower_dims* d, const ttv_batch* b, int layer) {
+  return latent_tail(d, b, layer) && b->qblocks_latent && b->n_qblocks_latent > 0 && b->clip_desc;
+}
+
 // ------------------------------------------------------------------------------------------------ forward (tape)
 static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, Tape& t, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
@@ -135,13 +141,18 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
     a.rope_cs = b->rope_cs; a.rope_q_end = dm; a.rope_k_begin = 2 * dm; a.rope_k_end = 2 * dm + g;
     a.rope_ids = b->rope_ids; a.rope_base = b->rope_ids ? b->rope_base : nullptr;
     TTV_TRY(ttvk_gemm(EPI_QKV_ROPE, a, s));
+    // encoder, last layer: attention outputs are needed for the latent query rows only (latent_attn); the raw output of the other rows is
+    // zeroed (the gate backward reads it for every row, times a zero gradient) and the backward skips those query rows too
+    const bool lat_q = latent_attn(d, b, i);
+    const int32_t* qb = lat_q ? b->qblocks_latent : b->qblocks;
+    const int nqb = lat_q ? b->n_qblocks_latent : b->n_qblocks;
+    const int pair = (!lat_q && b->qblocks_paired) ? TTV_ATTN_PAIRED : 0;
+    if (lat_q) (void)hipMemsetAsync(l.a, 0, (size_t)L * dm * esz(dt), s);
     if (dt == TTV_BF16) {
       // one launch writes the raw output a (tape) and the gated one ag = a * sigmoid(gate) (gate applied to the stored, rounded a)
-      TTV_TRY(ttvk_attention(l.qkvg, nq, l.ag, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
-                             TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0), dt, s, l.lse, l.a));
+      TTV_TRY(ttvk_attention(l.qkvg, nq, l.ag, dm, b->cu_seqlens, qb, nqb, d->q_heads, d->kv_heads, d->head_dim, TTV_ATTN_GATE | pair, dt, s, l.lse, l.a));
     } else {
-      TTV_TRY(ttvk_attention(l.qkvg, nq, l.a, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
-                             b->qblocks_paired ? TTV_ATTN_PAIRED : 0, dt, s, l.lse));
+      TTV_TRY(ttvk_attention(l.qkvg, nq, l.a, dm, b->cu_seqlens, qb, nqb, d->q_heads, d->kv_heads, d->head_dim, pair, dt, s, l.lse));
       TTV_TRY(ttvk_gate_fwd(l.a, dm, (const char*)l.qkvg + (size_t)dm * esz(dt), nq, l.ag, dm, L, dm, dt, s));
     }
     // the rest of the layer on (Lc rows: ag_in, x_in): every row, or - encoder, last layer - the latent rows, compact
@@ -284,7 +295,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
                           ws.delta, s));   // also fills delta = sum_d da * a per (row, head) for the attention backward
     // attention backward -> dq, dk, dv columns of dqkvg
     TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, ws.g_d, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
-                               ws.dkv, L, d->q_heads, d->kv_heads, dt, b->rope_cs, s, 1));   // dq, dk come back un-rotated; delta from the gate backward
+                               ws.dkv, L, d->q_heads, d->kv_heads, dt, b->rope_cs, s, 1, latent_attn(d, b, i) ? b->clip_desc : nullptr));   // dq, dk come back un-rotated; delta from the gate backward
     // dxn1 = dqkvg Wqkv ; dWqkv += dqkvg^T xn1
     GemmArgs q = {};
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
