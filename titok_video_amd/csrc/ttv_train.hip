@@ -56,6 +56,7 @@ struct BwdWs {
   float *dxa, *dxb, *delta, *dkv, *colsum, *small_f32;
   float* dxc;       // [sum_tokens, width] fp32: the latent rows of the residual-stream gradient, compact (encoder, last layer)
   char *g_d, *g_d2, *g_i, *g_2i, *g_nq, *g_pd;
+  char *g_df2, *g_do;   // [L, width]: the second df buffer (layers alternate) and do - operands the weight-gradient stream may still read
   float* wg_part;
   int64_t wg_part_bytes;
   int64_t total;
@@ -75,6 +76,7 @@ static BwdWs carve_bwd(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
   w.dxc = (float*)take((int64_t)b->sum_tokens * dm * 4);
   w.g_d = take(L * dm * e); w.g_d2 = take(L * dm * e); w.g_i = take(L * d->inner * e); w.g_2i = take(L * 2 * d->inner * e);
   w.g_nq = take(L * nq * e); w.g_pd = take(P * pd * e);
+  w.g_df2 = take(L * dm * e); w.g_do = take(L * dm * e);
   // split partial tiles of the weight-gradient GEMMs (largest of the shapes the tower uses)
   int64_t wgb = 0;
   if (d->dtype == TTV_BF16) {
@@ -217,6 +219,55 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
   return TTV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ weight-gradient stream
+// The weight-gradient GEMMs of a layer (dW = dY^T X, four per layer, plus the launch that sums their split partial tiles) are off the
+// backward's critical path: nothing of the layer reads them.  They run on a second HIP stream, forked from the caller's stream by an event
+// behind the producer of each dY and joined at the end of the layer, so that their launch tails and partly filled rounds overlap the
+// dX chain (and, at the reference's 5-clip batches, their launch latencies).  The caller's stream stays the only one the caller sees:
+// every fork is an event recorded on it, the join makes it wait - legal inside a HIP-graph capture of the step as well.
+// Operands the second stream reads are not overwritten before the join (df alternates between two buffers, do / da have their own).
+// TTV_WGRAD_SIDE=0: everything on the caller's stream (A/B).
+struct WgradSide {
+  hipStream_t w = nullptr;
+  hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t join = nullptr;
+  int state = 0;   // 0 not tried, 1 ready, -1 unavailable
+};
+static WgradSide* wgrad_side() {
+  static const bool on = !(getenv("TTV_WGRAD_SIDE") && getenv("TTV_WGRAD_SIDE")[0] == '0');
+  if (!on) return nullptr;
+  static thread_local WgradSide tab[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  WgradSide& sd = tab[dev];
+  if (sd.state == 0) {
+    sd.state = -1;
+    if (hipStreamCreateWithFlags(&sd.w, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i < 4; ++i)
+      if (hipEventCreateWithFlags(&sd.fork[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    sd.state = 1;
+  }
+  return sd.state == 1 ? &sd : nullptr;
+}
+// the second stream takes up the caller's stream at this point
+static int side_fork(WgradSide* sd, int k, hipStream_t s) {
+  if (!sd) return TTV_OK;
+  if (hipEventRecord(sd->fork[k], s) != hipSuccess || hipStreamWaitEvent(sd->w, sd->fork[k], 0) != hipSuccess) {
+    ttv_set_error("backward: fork of the weight-gradient stream failed");
+    return TTV_ERR_LAUNCH;
+  }
+  return TTV_OK;
+}
+static int side_join(WgradSide* sd, hipStream_t s) {
+  if (!sd) return TTV_OK;
+  if (hipEventRecord(sd->join, sd->w) != hipSuccess || hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) {
+    ttv_set_error("backward: join of the weight-gradient stream failed");
+    return TTV_ERR_LAUNCH;
+  }
+  return TTV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ backward (layers)
 // On entry ws.dxa holds dL/dX[layers] (fp32); on exit ws.dxa holds dL/dX[0].
 static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* b, Tape& t,
@@ -226,11 +277,18 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
   float* dx = ws.dxa;     // gradient of the layer output
   float* tmp = ws.dxb;
   WgradBatch wgb;
+  char* g_df[2] = {ws.g_d, ws.g_df2};   // df of this layer / da of this layer, then df of the layer below
+  int cur = 0;
   for (int i = d->layers - 1; i >= 0; --i) {
     const ttv_layer_weights& lw = w->layers[i];
     const ttv_layer_weights_t& lt = wt->layers[i];
     const ttv_layer_grads& lg = gr->layers[i];
     Tape::L& l = t.l[i];
+    // the layer's weight-gradient GEMMs and their summing launch: on the second stream (wgrad_side) when any is wanted
+    WgradSide* sd = (lg.w3 || lg.w12 || lg.out_proj || lg.to_qkv) ? wgrad_side() : nullptr;
+    const hipStream_t sw = sd ? sd->w : s;
+    char* const df = g_df[cur];
+    char* const da = g_df[cur ^ 1];
     // ---------------- feed-forward sub-layer: X[i+1] = post_ln(alpha*x1 + w3 h)  (layer 0: x1 + w3 h) ----------------
     // The top layer undoes its feed-forward post-norm here; for the layers below it was chained onto the pre_ln backward of the
     // layer above (end of the previous iteration).
@@ -249,34 +307,37 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
       if (i > 0) {
         TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, Lc, dm, d->eps, s));
         // tmp = dy2 ; df (T) = dy2 ; dx1 = alpha * dy2 (into dx)
-        TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, ws.g_d, dt, nLc, s));
+        TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, df, dt, nLc, s));
       } else {
-        TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, ws.g_d, dt, nLc, s));   // df = (T) dx ; dx1 = dx
+        TTV_TRY(ttvk_scale_cast(dx, 1.f, nullptr, df, dt, nLc, s));   // df = (T) dx ; dx1 = dx
       }
     }
     dx1 = dx;
     // dh = df W3 ; dW3 += df^T h
     GemmArgs a = {};
-    a.dtype = dt; a.x = ws.g_d; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = Lc; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
+    a.dtype = dt; a.x = df; a.ldx = dm; a.w = lt.w3_t; a.ldw = dm; a.M = Lc; a.N = I; a.K = dm; a.y = ws.g_i; a.ldy = I;
+    TTV_TRY(side_fork(sd, 0, s));          // df is complete
     TTV_TRY(ttvk_gemm(EPI_STORE, a, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, l.h, I, lg.w3, I, Lc, dm, I, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_wgrad(df, dm, l.h, I, lg.w3, I, Lc, dm, I, dt, ws.wg_part, ws.wg_part_bytes, sw, &wgb));
     TTV_TRY(ttvk_geglu_bwd(l.u, 2 * I, ws.g_i, I, ws.g_2i, 2 * I, Lc, I, dt, s));
+    TTV_TRY(side_fork(sd, 1, s));          // du is complete
     // dxn2 = du W12 ; dW12 += du^T xn2
     GemmArgs c = {};
     c.dtype = dt; c.x = ws.g_2i; c.ldx = 2 * I; c.w = lt.w12_t; c.ldw = 2 * I; c.M = Lc; c.N = dm; c.K = 2 * I; c.y = ws.g_d2; c.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, c, s));
-    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, Lc, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_wgrad(ws.g_2i, 2 * I, l.xn2, dm, lg.w12, dm, Lc, 2 * I, dm, dt, ws.wg_part, ws.wg_part_bytes, sw, &wgb));
     // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2), then straight through the attention sub-layer's post-norm:
     // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
     // i > 0: dy1 = rmsnorm_bwd(y1, attn_post_ln, dx1) ; do = (T) dy1 ; dx = alpha * dy1      i == 0: do = (T) dx1 ; dx = dx1
     TTV_TRY(ttvk_rmsnorm_bwd_chain(l.x1, dm, ws.g_d2, dm, lw.ffd_norm, lg.ffd_norm, dx1, dm, i > 0 ? l.y1 : nullptr, dm,
-                                   i > 0 ? lw.attn_post_ln : nullptr, i > 0 ? lg.attn_post_ln : nullptr, i > 0 ? d->alpha : 1.f, ws.g_d, dm, Lc,
+                                   i > 0 ? lw.attn_post_ln : nullptr, i > 0 ? lg.attn_post_ln : nullptr, i > 0 ? d->alpha : 1.f, ws.g_do, dm, Lc,
                                    dm, d->eps, dt, s));
+    TTV_TRY(side_fork(sd, 2, s));          // do is complete
     // dag = do Wo ; dWo += do^T ag
     GemmArgs e = {};
-    e.dtype = dt; e.x = ws.g_d; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = Lc; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
+    e.dtype = dt; e.x = ws.g_do; e.ldx = dm; e.w = lt.out_proj_t; e.ldw = dm; e.M = Lc; e.N = dm; e.K = dm; e.y = ws.g_d2; e.ldy = dm;
     TTV_TRY(ttvk_gemm(EPI_STORE, e, s));
-    TTV_TRY(ttvk_wgrad(ws.g_d, dm, lat ? t.agc : l.ag, dm, lg.out_proj, dm, Lc, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
+    TTV_TRY(ttvk_wgrad(ws.g_do, dm, lat ? t.agc : l.ag, dm, lg.out_proj, dm, Lc, dm, dm, dt, ws.wg_part, ws.wg_part_bytes, sw, &wgb));
     // back to every row: the gradient of the attention output and of the residual stream are zero outside the latent rows
     char* dag = ws.g_d2;
     if (lat) {
@@ -288,20 +349,21 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
       TTV_TRY(ttvk_copy_rows(ws.dxc, (int64_t)dm * 4, nullptr, dxf, (int64_t)dm * 4, b->latent_rows, Lc, dm * 4, s));
       dx = dxf;
     }
-    // da = dag*sigmoid(gate) (into g_d) ; dgate -> dqkvg[:, d:2d]
+    // da = dag*sigmoid(gate) (into the df buffer this layer does not use) ; dgate -> dqkvg[:, d:2d]
     char* dqkvg = ws.g_nq;
     const size_t es = esz(dt);
-    TTV_TRY(ttvk_gate_bwd(dag, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, ws.g_d, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt,
+    TTV_TRY(ttvk_gate_bwd(dag, dm, l.a, dm, (const char*)l.qkvg + (size_t)dm * es, nq, da, dm, dqkvg + (size_t)dm * es, nq, L, dm, dt,
                           ws.delta, s));   // also fills delta = sum_d da * a per (row, head) for the attention backward
     // attention backward -> dq, dk, dv columns of dqkvg
-    TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, ws.g_d, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
+    TTV_TRY(ttvk_attention_bwd(l.qkvg, nq, l.a, dm, da, dm, l.lse, ws.delta, b->cu_seqlens, b->blocks64, b->n_blocks64, b->row_seq, dqkvg, nq,
                                ws.dkv, L, d->q_heads, d->kv_heads, dt, b->rope_cs, s, 1, latent_attn(d, b, i) ? b->clip_desc : nullptr));   // dq, dk come back un-rotated; delta from the gate backward
     // dxn1 = dqkvg Wqkv ; dWqkv += dqkvg^T xn1
     GemmArgs q = {};
     q.dtype = dt; q.x = dqkvg; q.ldx = nq; q.w = lt.to_qkv_t; q.ldw = nq; q.M = L; q.N = dm; q.K = nq; q.y = ws.g_d2; q.ldy = dm;
+    TTV_TRY(side_fork(sd, 3, s));          // dqkvg is complete
     TTV_TRY(ttvk_gemm(EPI_STORE, q, s));
-    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, ws.wg_part, ws.wg_part_bytes, s, &wgb));
-    TTV_TRY(ttvk_wgrad_flush(&wgb, s));      // the layer's four weight gradients: one summing launch
+    TTV_TRY(ttvk_wgrad(dqkvg, nq, l.xn1, dm, lg.to_qkv, dm, L, nq, dm, dt, ws.wg_part, ws.wg_part_bytes, sw, &wgb));
+    TTV_TRY(ttvk_wgrad_flush(&wgb, sw));     // the layer's four weight gradients: one summing launch
     // dx += rmsnorm_bwd(X[i], pre_ln, dxn1) = dL/dX[i]; chained with the head of the layer below: through its feed-forward
     // post-norm (layers >= 1) and the bf16 copy df that its w3 products read
     if (i == 0) {
@@ -310,8 +372,10 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
       const bool post = i - 1 > 0;
       TTV_TRY(ttvk_rmsnorm_bwd_chain(t.X[i], dm, ws.g_d2, dm, lw.pre_ln, lg.pre_ln, dx, dm, post ? t.l[i - 1].y2 : nullptr, dm,
                                      post ? w->layers[i - 1].ffd_post_ln : nullptr, post ? gr->layers[i - 1].ffd_post_ln : nullptr,
-                                     post ? d->alpha : 1.f, ws.g_d, dm, L, dm, d->eps, dt, s));
+                                     post ? d->alpha : 1.f, g_df[cur ^ 1], dm, L, dm, d->eps, dt, s));   // df of the layer below (da is consumed)
     }
+    cur ^= 1;
+    TTV_TRY(side_join(sd, s));             // the caller's stream takes the weight gradients back in; dY operands may be overwritten from here
     // every gradient of layer i is final here (its ffd_post_ln gain received its contribution in the iteration above)
     if (gr->layer_done_events && gr->layer_done_events[i]) {
       if (hipEventRecord((hipEvent_t)gr->layer_done_events[i], s) != hipSuccess) {
