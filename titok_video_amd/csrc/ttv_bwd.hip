@@ -962,14 +962,22 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ dy,
 }
 
 static int wgrad_target_blocks() {
-  static const int v = getenv("TTV_WGRAD_BLOCKS") ? atoi(getenv("TTV_WGRAD_BLOCKS")) : 384;
+  static const int v = getenv("TTV_WGRAD_BLOCKS") ? atoi(getenv("TTV_WGRAD_BLOCKS")) : 256;
+  return v < 1 ? 1 : v;
+}
+static int wgrad_min_steps() {
+  static const int v = getenv("TTV_WGRAD_MIN_STEPS") ? atoi(getenv("TTV_WGRAD_MIN_STEPS")) : 16;
   return v < 1 ? 1 : v;
 }
 static void wgrad_plan(int L, int N, int K, int* splits, int* tpb) {
   const int nb = ttv_cdiv(N, 128) * ttv_cdiv(K, 128);
   // token ranges: a multiple of 8 (one per XCD and round), about wgrad_target_blocks() blocks in all - the per-block tile
-  // write-out is the fixed cost, so more blocks than ~2 per CU only add traffic
+  // write-out is the fixed cost, so more blocks than ~1 per CU only add traffic (256 since the GEMMs run beside the dX chain on
+  // their own stream, 384 before; tools/wgrad_plan_sweep.sh)
   int sp = 8 * ((wgrad_target_blocks() + 4 * nb) / (8 * nb));
+  // ... and a block should have wgrad_min_steps() 64-token steps to amortise its 64 KB partial tile (written here, read again by the sum)
+  const int cap = 8 * (L / (64 * wgrad_min_steps() * 8));
+  if (sp > cap) sp = cap;
   if (sp < 8) sp = 8;
   if (sp > ttv_cdiv(L, 64)) sp = ttv_cdiv(L, 64);
   if (sp < 1) sp = 1;
