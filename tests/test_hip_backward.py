@@ -351,6 +351,38 @@ def test_graphed_training_step_replays_the_eager_step():
         assert float((p - q).detach().abs().max()) < 2e-3 * max(1.0, float(p.detach().abs().max())), n
 
 
+
+_GRAD_DIGEST = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests.test_hip_backward import _hip_grads
+shapes, counts = [(4, 16, 16), (8, 32, 48), (4, 8, 24), (16, 64, 64)], [2, 5, 3, 40]
+loss, idx, model, clips = _hip_grads(torch.bfloat16, shapes, counts, 31)
+h = hashlib.sha256()
+for name, p in sorted(model.named_parameters()):
+    if any(k in name for k in ("to_qkv", "out_proj", "w12", "w3")) and name.endswith("weight"):
+        h.update(name.encode()); h.update(p.grad.float().cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), float(loss))
+"""
+
+
+def test_weight_gradient_stream_changes_no_bit():
+    """The layers' weight-gradient GEMMs run on a second stream beside the dX chain (ttv_train.hip, wgrad_side); the switch
+    TTV_WGRAD_SIDE=0 keeps them on the caller's stream.  Same kernels, same split plan, same summing order: the gradients of every
+    layer linear must be bit-identical (a missing dependency between the streams would show as a difference).  The switch is read once
+    per process and the backward runs on autograd's own thread, so the two settings run in child processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for side in ("1", "0"):
+        env = dict(os.environ, TTV_WGRAD_SIDE=side)
+        out = subprocess.run([sys.executable, "-c", _GRAD_DIGEST, root], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1], digests
+
+
 def test_mixed_precision_training_step_fp32_master_weights_bf16_compute():
     """The reference trains bf16-mixed (fp32 parameters, bf16 autocast).  Here the compute dtype of a tower is the dtype of the
     clips it is given and the weight pack holds compute-dtype copies of the parameters, so fp32 parameters + bf16 clips IS that mode:
