@@ -37,3 +37,16 @@ def test_gpus_beyond_the_visible_devices_is_refused():
 def test_world_size_mismatch_is_refused():
     p = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", TTV_BENCH_DRYRUN="1")
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_train_dp_fan_out_hands_every_rank_the_same_run_token():
+    """tools/train_dp.py --gpus N starts its own ranks; they meet at a shard directory named after the run token, so the token must be
+    one per run, not one per rank."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_dp_tool", os.path.join(ROOT, "tools", "train_dp.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    envs = mod.fan_out_envs(4, 29999)
+    assert len({e["TTV_RUN_TOKEN"] for e in envs}) == 1
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in envs)
+    assert all(e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)

@@ -226,16 +226,19 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
 // dX chain (and, at the reference's 5-clip batches, their launch latencies).  The caller's stream stays the only one the caller sees:
 // every fork is an event recorded on it, the join makes it wait - legal inside a HIP-graph capture of the step as well.
 // Operands the second stream reads are not overwritten before the join (df alternates between two buffers, do / da have their own).
-// TTV_WGRAD_SIDE=0: everything on the caller's stream (A/B).
+// TTV_WGRAD_SIDE=0: everything on the caller's stream (A/B); see wgrad_side for the DP default.
 struct WgradSide {
   hipStream_t w = nullptr;
   hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t join = nullptr;
   int state = 0;   // 0 not tried, 1 ready, -1 unavailable
 };
-static WgradSide* wgrad_side() {
-  static const bool on = !(getenv("TTV_WGRAD_SIDE") && getenv("TTV_WGRAD_SIDE")[0] == '0');
-  if (!on) return nullptr;
+static WgradSide* wgrad_side(bool dp) {
+  // 1 (default): single-process steps; 2: also with the DP path's per-layer events attached; 0: never.  Default off under DP: the
+  // two-rank test (tests/test_hip_config3.py) had ONE red run in 15 with the second stream on and none in 5 with it off - not
+  // reproduced, cause unknown, so the path whose ranks must agree bit for bit keeps the one-stream backward
+  static const int mode = getenv("TTV_WGRAD_SIDE") ? atoi(getenv("TTV_WGRAD_SIDE")) : 1;
+  if (mode <= 0 || (dp && mode < 2)) return nullptr;
   static thread_local WgradSide tab[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -285,7 +288,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     const ttv_layer_grads& lg = gr->layers[i];
     Tape::L& l = t.l[i];
     // the layer's weight-gradient GEMMs and their summing launch: on the second stream (wgrad_side) when any is wanted
-    WgradSide* sd = (lg.w3 || lg.w12 || lg.out_proj || lg.to_qkv) ? wgrad_side() : nullptr;
+    WgradSide* sd = (lg.w3 || lg.w12 || lg.out_proj || lg.to_qkv) ? wgrad_side(gr->layer_done_events != nullptr) : nullptr;
     const hipStream_t sw = sd ? sd->w : s;
     char* const df = g_df[cur];
     char* const da = g_df[cur ^ 1];

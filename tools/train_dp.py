@@ -25,6 +25,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def fan_out_envs(n, port):
+    """Environments of the n ranks this script starts by itself: torchrun's variables plus ONE run token shared by all of them (it names
+    the shard directory rank 0 writes and the others wait for; a token per rank - the clock read once per Popen - left every rank but 0
+    waiting for a directory that never came, round 4)."""
+    token = "%d_%d_%d" % (os.getpid(), port, int(time.time() * 1e3))
+    return [dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 HSA_ENABLE_IPC_MODE_LEGACY="0", TTV_RUN_TOKEN=token) for r in range(n)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=0, help="without a launcher (WORLD_SIZE unset): start this many ranks, one per GPU")
@@ -52,15 +61,15 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                  env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                                           MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                                           TTV_RUN_TOKEN="%d_%d_%d" % (os.getpid(), port, int(time.time() * 1e3)))) for r in range(args.gpus)]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env) for env in fan_out_envs(args.gpus, port)]
         codes = [p.wait() for p in procs]
         if any(codes):
             raise SystemExit(f"train_dp.py --gpus {args.gpus}: rank exit codes {codes}")
         return
 
+    if os.environ.get("TTV_HANG_DUMP"):         # diagnostics: every thread's stack to stderr after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TTV_HANG_DUMP"]), exit=True)
     import torch.distributed as dist
     from titok_video_amd import dp
     from titok_video_amd.codebook import CodebookLogger
@@ -111,8 +120,8 @@ def main():
                         break
                 except OSError:
                     pass
-                if time.time() - t_wait > 600:
-                    raise SystemExit("train_dp.py: rank 0 never finished writing the shards")
+                if time.time() - t_wait > 120:
+                    raise SystemExit("train_dp.py: rank 0 never finished writing the shards (waited 120 s for %s to hold this run's token)" % marker)
                 time.sleep(0.05)
     paths = sorted(os.path.join(shard_dir, f) for f in os.listdir(shard_dir) if f.endswith(".tar"))[:n_shards]
     loader = ShardBatchLoader(paths, rank, world, patch=(4, 8, 8), token_range=(1, 128), seq_len=args.seq_len, seed=100 + rank,
