@@ -235,7 +235,7 @@ struct WgradSide {
 };
 static WgradSide* wgrad_side(bool dp) {
   // 1 (default): single-process steps; 2: also with the DP path's per-layer events attached; 0: never.  Default off under DP: the
-  // two-rank test (tests/test_hip_config3.py) had ONE red run in 15 with the second stream on and none in 5 with it off - not
+  // two-rank test (tests/test_hip_config3.py) had ONE red run in 31 with the second stream on and none in 5 with it off - not
   // reproduced, cause unknown, so the path whose ranks must agree bit for bit keeps the one-stream backward
   static const int mode = getenv("TTV_WGRAD_SIDE") ? atoi(getenv("TTV_WGRAD_SIDE")) : 1;
   if (mode <= 0 || (dp && mode < 2)) return nullptr;
