@@ -170,3 +170,17 @@ def test_attention_table64_covers_every_row_slice_once():
     # the benchmark batch: 32 x 1152 rows, 4/2 heads -> 576 workgroups, no idle wave
     big = BatchPlan([(16, 128, 128)] * 32, [128] * 32, (4, 8, 8), "cpu").attention_table64(4, 2).numpy()
     assert big.shape[0] == 576 and (big[:, 2:6] >= 0).all()
+
+
+def test_attention_backward_blocks_are_a_permutation_grouped_by_xcd():
+    """plan._xcd_interleave: every (sequence, first row) block appears exactly once; for a uniform batch every sequence's blocks sit in
+    one residue class of the table index modulo 8 (one XCD under round-robin dispatch); ragged batches keep the permutation property."""
+    from titok_video_amd.plan import _xcd_interleave
+    units = [[(b, r) for r in range(0, 1152, 64)] for b in range(32)]
+    t = _xcd_interleave(units)
+    assert sorted(map(tuple, t.tolist())) == sorted(e for u in units for e in u)
+    for b in range(32):
+        assert len({i % 8 for i in range(len(t)) if t[i, 0] == b}) == 1
+    ragged = [[(b, r) for r in range(0, n, 64)] for b, n in enumerate([100, 1152, 64, 700, 33, 2000, 65, 640, 9, 1281])]
+    t = _xcd_interleave(ragged)
+    assert sorted(map(tuple, t.tolist())) == sorted(e for u in ragged for e in u)

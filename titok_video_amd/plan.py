@@ -114,6 +114,28 @@ def _rope_clip_table(grid: Tuple[int, ...], k: int, head_dim: int) -> np.ndarray
     return out
 
 
+def _xcd_interleave(units) -> np.ndarray:
+    """(sequence, first row) entries of the attention backward's 64-row blocks, ordered for the 8 XCDs: block b of a launch runs on XCD
+    b % 8 under round-robin dispatch (a speed assumption only), and every block of a sequence streams that sequence's Q / dO (key
+    blocks) or K / V (query blocks) tiles.  In sequence-major order one sequence's blocks were dealt over all 8 XCDs, every XCD's
+    4 MB L2 saw every sequence, and the launch fetched 674 MB from HBM / MALL for ~100 MB of operands at the benchmark batch
+    (profiles/r04_train_pmc.txt).  Sequences go to 8 lists (greedy by block count), entry i of the table comes from list i % 8; when the
+    short lists run out the rest follows in list order (no padding entries: the kernels take the table as it is)."""
+    if os.environ.get("TTV_BWD_XCD", "1") == "0":       # A/B: sequence-major order
+        return np.asarray([e for u in units for e in u], dtype=np.int32).reshape(-1, 2)
+    order = sorted(range(len(units)), key=lambda i: len(units[i]), reverse=True)
+    lists, weight = [[] for _ in range(8)], [0] * 8
+    for i in order:
+        x = min(range(8), key=lambda j: weight[j])
+        lists[x].extend(units[i])
+        weight[x] += len(units[i])
+    depth = min(len(l) for l in lists)
+    out = [lists[x][k] for k in range(depth) for x in range(8)]
+    for l in lists:
+        out.extend(l[depth:])
+    return np.asarray(out, dtype=np.int32).reshape(-1, 2)
+
+
 class BatchPlan:
     """Device tables + the ttv_batch struct for one (clip shapes, token counts) combination."""
 
@@ -170,7 +192,7 @@ class BatchPlan:
             coords = np.indices(grids[b]).reshape(len(grids[b]), -1).T      # raster order (t, h, w)
             ids[cu[b] + k:cu[b + 1], :3] = np.minimum(coords + k, n_ids - 1).astype(np.uint16)
         rope_ids = ids.view(np.int32).reshape(-1)
-        blocks64 = np.asarray([(b, r0) for b in range(B) for r0 in range(0, cu[b + 1] - cu[b], 64)], dtype=np.int32).reshape(-1, 2)
+        blocks64 = _xcd_interleave([[(b, r0) for r0 in range(0, cu[b + 1] - cu[b], 64)] for b in range(B)])
         row_seq = np.concatenate([np.full(cu[b + 1] - cu[b], b, dtype=np.int32) for b in range(B)])
         self.n_blocks64 = int(blocks64.shape[0])
         parts = [np.asarray(cu, dtype=np.int32), latent_rows, patch_rows, desc.reshape(-1), blocks64.reshape(-1), row_seq, rope_ids]
