@@ -1221,7 +1221,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd_f32(const float* __restrict__ 
 // ---- bf16 MFMA kernels.  LDS tiles are row-major [64 rows][64 cols] bf16 with 128-byte rows; the 16-byte chunk c of row r
 // is stored at chunk position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 fragment read touches then cover all 64
 // banks once (unswizzled they fall on two 4-bank groups, 8-way), and the transposed reads drop from 4-way to 2-way. ----
+// chunk swizzle of the 64 x 64 tiles (128-byte rows: rows r and r + 2 share their banks), m = (row >> 1) & 7.  Plain m keeps the b128 row
+// reads (16 lanes = 16 rows of one chunk) conflict-free but only swaps the two chunks of a 32-byte pair between rows r and r + 2, and the
+// transposed reads (frag_colp: 16 lanes = 4 consecutive rows x 32 bytes) then run at half rate: SQ_LDS_BANK_CONFLICT was 26 % of
+// k_attn_bwd's LDS-active cycles (profiles/r04_train_sq.txt).  This permutation of m puts rows r, r + 2, r + 4, r + 6 on four different pairs
+// and still gives the eight rows of one parity eight different chunks; both read kinds at full rate (tools/ubench/lds_rates.hip,
+// profiles/r04_lds_rates_attn_bwd.txt: 123 -> 218 bytes / cycle / CU for the transposed reads, 223 -> 225 for the row reads; the simpler
+// ((m & 3) << 1) | (m >> 2) fixes the first and halves the second).  -DTTV_TSW_OLD: plain m (A/B).
+#ifdef TTV_TSW_OLD
 #define TSW(r_) (((r_) >> 1) & 7)
+#else
+#define TSW(r_) ((((((r_) >> 1) & 1) | (((((r_) >> 2) ^ ((r_) >> 3)) & 1) << 1)) << 1) | (((r_) >> 3) & 1))
+#endif
 // fragment with 8 consecutive COLUMNS of one row (K-contiguous operand): rows r0+l15, columns kc*8.. (b128)
 __device__ __forceinline__ bf16x8 frag_row(const uint4* tile, int row, int chunk) { return __builtin_bit_cast(bf16x8, tile[row * 8 + (chunk ^ TSW(row))]); }
 // fragment with 8 consecutive ROWS (row0 + 8*kq + 0..7) of one column col0 + l15: two transposed reads

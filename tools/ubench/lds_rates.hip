@@ -32,6 +32,23 @@ __global__ void k(unsigned* out, long long* cyc, int iters) {
   const int vlane = (4 * h + tq) * 128 + (g16 * 2 + (tp >> 1)) * 16 + (tp & 1) * 8;
   const unsigned vo0 = lds0 + 16384 + vlane + (vsw ? 64 : 0), vo1 = lds0 + 16384 + vlane + (vsw ? 0 : 64);
   const unsigned lin16 = lds0 + lane * 16, lin8 = lds0 + lane * 8, lin4 = lds0 + lane * 4;
+  // the attention backward's 64 x 64 tiles (ttv_bwd.hip: 128-byte rows, chunk swizzle TSW(row)): frag_colp's transposed reads (16 lanes = 4
+  // consecutive rows x 32 bytes; second read 16 rows on) and frag_row's b128 reads (16 lanes = 16 rows of one chunk), under three swizzles:
+  //   SW 0: (r >> 1) & 7 (the kernel's)   SW 1: ((r >> 1) & 3) << 1 | (r >> 3) & 1   SW 2: pairs by (m & 1) | ((m >> 1 ^ m >> 2) & 1) << 1, m = (r >> 1) & 7
+  constexpr int SW = (KIND >= 7) ? (KIND - 7) % 3 : 0;
+  auto tsw = [](int r_) {
+    const int m = (r_ >> 1) & 7;
+    return SW == 0 ? m : SW == 1 ? (((m & 3) << 1) | (m >> 2)) : ((((m & 1) | ((((m >> 1) ^ (m >> 2)) & 1) << 1)) << 1) | (m >> 2));
+  };
+  const int bkq = lane >> 4, bl15 = lane & 15;
+  unsigned cp[4], rw[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = bkq * 4 + tq, cc = i * 16 + tp * 4;
+    cp[i] = lds0 + rr * 128 + ((((cc >> 3) ^ tsw(rr)) << 4) | ((cc & 7) << 1));      // rows rr + 16 / + 32 / + 48 have the same swizzle value: plain offsets
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) rw[ks] = lds0 + bl15 * 128 + (((ks * 4 + bkq) ^ tsw(bl15)) << 4);        // rows + 16: same swizzle
   __syncthreads();
   unsigned vx = 0;
   long long t0 = __builtin_readcyclecounter();
@@ -98,6 +115,30 @@ __global__ void k(unsigned* out, long long* cyc, int iters) {
       for (int i = 0; i < 8; ++i) vx ^= q[i].x ^ q[i].w;
 #pragma unroll
       for (int i = 0; i < 16; ++i) vx ^= p[i].x ^ p[i].y;
+    }
+    if (KIND >= 7 && KIND <= 9) {   // 32 transposed reads of the attention backward (frag_colp on two tiles, both halves of the rows; 16 KB per wave)
+      u32x2 q[32];
+      RD64T(q[0], cp[0], 0); RD64T(q[1], cp[0], 2048); RD64T(q[2], cp[1], 0); RD64T(q[3], cp[1], 2048);
+      RD64T(q[4], cp[2], 0); RD64T(q[5], cp[2], 2048); RD64T(q[6], cp[3], 0); RD64T(q[7], cp[3], 2048);
+      RD64T(q[8], cp[0], 4096); RD64T(q[9], cp[0], 6144); RD64T(q[10], cp[1], 4096); RD64T(q[11], cp[1], 6144);
+      RD64T(q[12], cp[2], 4096); RD64T(q[13], cp[2], 6144); RD64T(q[14], cp[3], 4096); RD64T(q[15], cp[3], 6144);
+      RD64T(q[16], cp[0], 8192); RD64T(q[17], cp[0], 10240); RD64T(q[18], cp[1], 8192); RD64T(q[19], cp[1], 10240);
+      RD64T(q[20], cp[2], 8192); RD64T(q[21], cp[2], 10240); RD64T(q[22], cp[3], 8192); RD64T(q[23], cp[3], 10240);
+      RD64T(q[24], cp[0], 12288); RD64T(q[25], cp[0], 14336); RD64T(q[26], cp[1], 12288); RD64T(q[27], cp[1], 14336);
+      RD64T(q[28], cp[2], 12288); RD64T(q[29], cp[2], 14336); RD64T(q[30], cp[3], 12288); RD64T(q[31], cp[3], 14336);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 32; ++i) vx ^= q[i].x ^ q[i].y;
+    }
+    if (KIND >= 10 && KIND <= 12) { // 16 b128 row-fragment reads of the attention backward (frag_row: two k-steps x 16-row groups; 16 KB per wave)
+      u32x4 q[16];
+      RD128(q[0], rw[0], 0); RD128(q[1], rw[1], 0); RD128(q[2], rw[0], 2048); RD128(q[3], rw[1], 2048);
+      RD128(q[4], rw[0], 4096); RD128(q[5], rw[1], 4096); RD128(q[6], rw[0], 6144); RD128(q[7], rw[1], 6144);
+      RD128(q[8], rw[0], 8192); RD128(q[9], rw[1], 8192); RD128(q[10], rw[0], 10240); RD128(q[11], rw[1], 10240);
+      RD128(q[12], rw[0], 12288); RD128(q[13], rw[1], 12288); RD128(q[14], rw[0], 14336); RD128(q[15], rw[1], 14336);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vx ^= q[i].x ^ q[i].w;
     }
     if (KIND == 5) {            // 32 ds_read_b32, lanes linear (8 KB per wave)
       unsigned q[32];
@@ -172,5 +213,11 @@ int main() {
   run<6>("the same bytes as 32 ds_read_b64", 16384);
   run<3>("32 ds_read_b64_tr_b16, attention V^T fragment pattern", 16384);
   run<4>("one attention tile: 8 K reads + 16 V^T reads", 16384);
+  run<7>("attention backward: 32 transposed reads, swizzle (r>>1)&7", 16384);
+  run<8>("attention backward: 32 transposed reads, swizzle pairs by (r>>1)&3", 16384);
+  run<9>("attention backward: 32 transposed reads, swizzle pairs mixed", 16384);
+  run<10>("attention backward: 16 b128 row reads, swizzle (r>>1)&7", 16384);
+  run<11>("attention backward: 16 b128 row reads, swizzle pairs by (r>>1)&3", 16384);
+  run<12>("attention backward: 16 b128 row reads, swizzle pairs mixed", 16384);
   return 0;
 }
