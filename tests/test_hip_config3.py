@@ -4,7 +4,7 @@ Four small shards are written; two ranks (both on cuda:0, gloo for the collectiv
 reference's generator step (train.py:65-83: forward, L1, backward, clip 1.0, AdamW) from their own shards through the process-based
 loader (titok_video_amd/loader.py: worker processes -> shared memory -> pinned staging -> GPU normalisation), gradients reduced
 behind the backward (dp.GradReducer), token indices logged (CodebookLogger).  One process then runs the same steps on the UNION of
-the two ranks' batches.  After N steps the parameters agree to 1e-4 (relative; fp32 kernels accumulate with atomics) and the
+the two ranks' batches.  After N steps the parameters agree to 1e-4 (relative; fp32 kernels accumulate with atomics; see the tolerance note in the test) and the
 codebook histogram exactly.  (The discriminator step of tools/train_dp.py draws fresh noise per rank, so the comparable quantity is
 the generator step.)  `-m gpu`."""
 import os
@@ -110,9 +110,17 @@ def test_two_rank_shard_training_equals_one_process_on_the_union(tmp_path):
         assert keys1[st] == [res[0][2][st], res[1][2][st]]
     assert set(res[0][2][0]).isdisjoint(res[1][2][0])                      # rank-disjoint shards
     # both ranks hold identical weights; they equal the single-process weights
+    # Tolerance: the fp32 weight-gradient kernels accumulate with atomics, so a gradient element differs by ~1e-7 of its size from run
+    # to run.  AdamW divides by sqrt(v) + eps: for the odd element whose gradient is itself that small (|g| ~ eps = 1e-8) the normalised
+    # update is noise and two runs can move it by up to lr (1 + wd |p|) per step in different directions (seen once in ~35 runs: ONE
+    # element of encoder.proj_in.weight off by 0.8 lr).  So: all but one element (or a 1e-5 fraction) of every tensor within 1e-4 of its scale, and no
+    # element further apart than the optimizer can move it in STEPS steps.
+    lr = 1e-4                                                              # train.make_optimizer's default (configs/tiny.yaml)
     for n in params1:
         assert np.array_equal(res[0][0][n], res[1][0][n]), n
         scale = float(np.abs(params1[n]).max()) + 1e-12
-        assert float(np.abs(res[0][0][n] - params1[n]).max()) < 1e-4 * scale, n
+        diff = np.abs(res[0][0][n] - params1[n])
+        assert int((diff >= 1e-4 * scale).sum()) <= max(1, int(1e-5 * diff.size)), (n, float(diff.max()), scale)
+        assert float(diff.max()) <= 2.2 * lr * STEPS, (n, float(diff.max()))
     # codebook usage: the sum of the ranks' histograms is the single logger's histogram, exactly
     assert np.array_equal(res[0][1] + res[1][1], hist1) and int(hist1.sum()) > 0

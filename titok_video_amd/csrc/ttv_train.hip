@@ -226,7 +226,7 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
 // dX chain (and, at the reference's 5-clip batches, their launch latencies).  The caller's stream stays the only one the caller sees:
 // every fork is an event recorded on it, the join makes it wait - legal inside a HIP-graph capture of the step as well.
 // Operands the second stream reads are not overwritten before the join (df alternates between two buffers, do / da have their own).
-// TTV_WGRAD_SIDE=0: everything on the caller's stream (A/B); see wgrad_side for the DP default.
+// TTV_WGRAD_SIDE=0: everything on the caller's stream (A/B).
 struct WgradSide {
   hipStream_t w = nullptr;
   hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -234,11 +234,11 @@ struct WgradSide {
   int state = 0;   // 0 not tried, 1 ready, -1 unavailable
 };
 static WgradSide* wgrad_side(bool dp) {
-  // 1 (default): single-process steps; 2: also with the DP path's per-layer events attached; 0: never.  Default off under DP: the
-  // two-rank test (tests/test_hip_config3.py) had ONE red run in 31 with the second stream on and none in 5 with it off - not
-  // reproduced, cause unknown, so the path whose ranks must agree bit for bit keeps the one-stream backward
+  // 1 (default): on, also with the DP path's per-layer events attached; 0: never; 3: single-process steps only.  (For a while the DP
+  // path kept the one-stream backward after a red run of the two-rank test; that run turned out to be the test's own tolerance - an
+  // AdamW update of a near-zero gradient element is rounding noise - and showed up again with this stream off: DESIGN 5b.)
   static const int mode = getenv("TTV_WGRAD_SIDE") ? atoi(getenv("TTV_WGRAD_SIDE")) : 1;
-  if (mode <= 0 || (dp && mode < 2)) return nullptr;
+  if (mode <= 0 || (dp && mode == 3)) return nullptr;
   static thread_local WgradSide tab[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
