@@ -244,8 +244,9 @@ typedef struct ttv_tower_dims {
   int32_t inner;         /* GEGLU hidden I                      transformer.py:39-40 */
   int32_t patch_t, patch_h, patch_w;
   int32_t pix_channels;  /* 3 */
-  int32_t token_size;    /* len(fsq_levels) (encoder out / decoder in); 1 for the discriminator use; up to TTV_MAX_TOKEN for inference
-                            towers in front of / behind ttv_vq_l2_argmin (the training entry points take <= TTV_MAX_FSQ) */
+  int32_t token_size;    /* len(fsq_levels) (encoder out / decoder in); 1 for the discriminator use; up to TTV_MAX_TOKEN for the
+                            towers in front of / behind ttv_vq_l2_argmin, inference and training alike (the L2 quantiser trains since
+                            round 4: ttv_train.hip's check() accepts token_size <= TTV_MAX_TOKEN) */
   float eps;             /* RMSNorm eps 1e-5 */
   float alpha;           /* KEEL residual scale 2*layers        transformer.py:117 */
 } ttv_tower_dims;

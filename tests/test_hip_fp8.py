@@ -328,3 +328,51 @@ def test_mx_quantisation_fused_into_the_producers_is_bit_identical():
         outs.append((z, [r.clone() for r in recon], info["indices"].clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+def test_mx_tower_layer_off_the_mx_path_reads_the_folded_bf16_weights_not_the_mx_images():
+    """A layer of an MX tower that does not run run_layer_mx - the encoder's last layer, which works on the latent rows only
+    (ttv_batch.qblocks_latent) - must take its projections from the folded bf16 weights: the e4m3 pointers of an MX tower hold the
+    BLOCK-scaled image of W * gain, which the row-scaled GEMM of the generic path would read with the pre-norm gain applied twice and the
+    E8M0 block scales dropped (round-4 advisor finding).  Synthetic weights hide that (gains 1 +- 0.1, blocks of equal magnitude), so this
+    test gives the last encoder layer pre-norm gains around 2 and outlier input channels (a 32-column block 8x larger than its
+    neighbours: block exponents differ by 3) and compares the latent-rows forward with the all-rows, all-MX forward (ttv_debug_set
+    bit 19) and with the fp32 oracle.  The two differ by one layer's e4m3 noise; the misuse would be a factor ~2."""
+    levels = [8, 8, 8, 6, 5]
+    sd = seeded_titok_state(3, "base", "base", gain=3.0)
+    last = 11
+    g = torch.Generator().manual_seed(5)
+    for name in (f"encoder.model_layers.attn_layer.{last}.pre_ln.weight", f"encoder.model_layers.ffd_layer.{last}.norm.weight"):
+        sd[name] = sd[name] * (2.0 + 0.5 * torch.rand(sd[name].shape, generator=g))
+    for name in (f"encoder.model_layers.attn_layer.{last}.to_qkv.weight", f"encoder.model_layers.ffd_layer.{last}.w12.weight"):
+        w = sd[name].clone()
+        w[:, 64:96] *= 8.0            # one 32-column block of every row: its E8M0 scale sits 3 above the row's other blocks
+        w[:, 400:432] *= 0.125
+        sd[name] = w
+    shapes, counts = [(4, 16, 16), (8, 16, 24), (4, 32, 16)], [16, 24, 20]
+    clips_cpu = synthetic_clips(shapes, seed=13)
+    with torch.no_grad():
+        _recon, _idx, _zq, ref_b = O.titok_forward(clips_cpu, counts, sd, levels, "base", "base")
+    m = TiTok(_base_cfg(levels))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV, torch.bfloat16).eval()
+    m.encoder.fp8_linears = m.decoder.fp8_linears = "mx"
+    clips = [c.to(DEV, torch.bfloat16) for c in clips_cpu]
+    outs = {}
+    for bits in (0, 1 << 19):
+        _lib.lib().ttv_debug_set(bits)
+        try:
+            with torch.no_grad():
+                m.encode(clips, counts, want_bounded=True)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().ttv_debug_set(0)
+        outs[bits] = m.last_bounded.float().cpu()
+    e_lat = float((outs[0] - ref_b).abs().mean())
+    e_all = float((outs[1 << 19] - ref_b).abs().mean())
+    d = float((outs[0] - outs[1 << 19]).abs().mean())
+    print(f"MX encoder, last layer on latent rows (bf16 kernels): mean |bounded err| {e_lat:.4f}; all rows on the MX kernels: {e_all:.4f}; "
+          f"between the two: {d:.4f}")
+    assert not torch.equal(outs[0], outs[1 << 19])      # the shortcut really took the other kernels
+    assert e_all < 0.30, e_all
+    assert e_lat < 0.30 and e_lat < 1.5 * e_all + 0.02, (e_lat, e_all)

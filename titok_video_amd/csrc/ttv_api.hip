@@ -164,6 +164,13 @@ static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, co
   return TTV_OK;
 }
 
+// Does a linear of the generic layer path run on the row-scaled e4m3 image (round 2's mixed bf16 / fp8 mode)?  Only when the image IS
+// row-scaled: `mx` set means the pointers hold the block-scaled image of W * gain, which the row-scaled GEMM would mis-read (gain applied
+// twice, block scales dropped).
+static bool rows_f8(int dt, int dm, const void* img, const void* row_scale, const void* mx, const void* folded) {
+  return dt == TTV_BF16 && img && row_scale && !mx && dm % 128 == 0 && !(dm == 256 && folded);
+}
+
 // One ResidualAttentionBlock stack (reference transformer.py:126-146) on ws.x in place.
 static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_batch* b, const TowerWs& ws, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype;
@@ -200,8 +207,11 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     // ---- attention sub-layer (transformer.py:85-104) ----
     // mixed bf16 / fp8 (config #5): the pre-norm output is quantised to e4m3 per token (into the xn buffer: L x dm bytes of values,
     // then L fp32 scales) and the projection runs on the fp8 MFMA; everything downstream is unchanged
-    const bool f8_qkv = dt == TTV_BF16 && lw.to_qkv_f8 && lw.to_qkv_f8_scale && dm % 128 == 0 && !(dm == 256 && lw.to_qkv_pn);
-    const bool f8_w12 = dt == TTV_BF16 && lw.w12_f8 && lw.w12_f8_scale && dm % 128 == 0 && !(dm == 256 && lw.w12_pn);
+    // NOT when the images are the block-scaled ones (to_qkv_mx / w12_mx set: e4m3 of W * gain divided by the row factor AND the per-32
+    // E8M0 scales, which only run_layer_mx's GEMMs undo): a layer of an MX tower that lands here - the encoder's latent-only last layer,
+    // every layer under TTV_KEEL_F32SUM=1 - runs its projections on the bf16 kernels from the folded weights
+    const bool f8_qkv = rows_f8(dt, dm, lw.to_qkv_f8, lw.to_qkv_f8_scale, lw.to_qkv_mx, lw.to_qkv_pn);
+    const bool f8_w12 = rows_f8(dt, dm, lw.w12_f8, lw.w12_f8_scale, lw.w12_mx, lw.w12_pn);
     float* const f8_scales = reinterpret_cast<float*>(ws.xn + (((size_t)L * dm + 255) & ~(size_t)255));
     if (!qkv_ready && f8_qkv) {
       TTV_TRY(ttvk_quant_rows_fp8(ws.x, dt, dm, lw.pre_ln, d->eps, ws.xn, dm, f8_scales, L, dm, s));
@@ -333,7 +343,8 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       f3.alpha = d->alpha; f3.y = cx; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
-      const bool want = gen_ok && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn && !(w->layers[i + 1].to_qkv_f8 && w->layers[i + 1].to_qkv_f8_scale);
+      const bool want = gen_ok && i + 1 < d->layers && w->layers[i + 1].to_qkv_pn &&
+                        !rows_f8(dt, dm, w->layers[i + 1].to_qkv_f8, w->layers[i + 1].to_qkv_f8_scale, w->layers[i + 1].to_qkv_mx, w->layers[i + 1].to_qkv_pn);
       if (dt == TTV_BF16 && !keel_f32sum) {      // see the attention sub-layer above
         f3.alpha = d->alpha; f3.y = cx; f3.ldy = dm;
         TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));

@@ -1331,7 +1331,7 @@ __device__ __forceinline__ void attn_bwd_dkv_block(uint4* tiles, float (*ls)[2][
       dma_f32x64(ls_lds + (buf_) * 512 + 256, delta, vo__);                                                 \
     }                                                                                                       \
   } while (0)
-  DKV_ISSUE(0, 0);
+  if (nsteps > 0) DKV_ISSUE(0, 0);      // a clip without gradient-carrying query rows (K_b = 0 under the latent tail): dK = dV = 0, nothing staged
   bf16x8 bk[2][2], bv[2][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
