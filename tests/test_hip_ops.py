@@ -497,11 +497,12 @@ def test_layer_tail_fused(M, keel, back):
 @pytest.mark.parametrize("heads", [(4, 2), (12, 4)])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("paired", [0, 2])
-@pytest.mark.parametrize("qscaled", [0, 4, 4 | 8 | 16])
+@pytest.mark.parametrize("qscaled", [0, 4, 4 | 8, 4 | 8 | 16])
 def test_attention_varlen_gqa_gate(dt, case, heads, split, paired, qscaled):
     shapes, counts = case
-    if qscaled & 8 and (split or paired):     # TTV_ATTN_ALLFULL | TTV_ATTN_PIPE: the software-pipelined kernel, tables of full items only
-        pytest.skip("the pipelined kernel takes full items, unpaired")
+    # TTV_ATTN_QSCALED | TTV_ATTN_ALLFULL: k_attn_swp (ttv_attn_swp.hip, the default for such tables); with TTV_ATTN_PIPE: k_attn_pipe
+    if qscaled & 8 and (split or paired):
+        pytest.skip("the pipelined kernels take full items, unpaired")
     plan = BatchPlan(shapes, counts, (4, 8, 8), DEV)
     hq, hkv = heads
     if paired and ((hq // hkv) % 2 or dt != "bf16"):
@@ -534,9 +535,10 @@ def test_attention_varlen_gqa_gate(dt, case, heads, split, paired, qscaled):
 
 
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("qscaled", [0, 4, 4 | 8 | 16])
-@pytest.mark.parametrize("spike", [6.0, 30.0])
-def test_attention_online_softmax_rescale_branch(split, qscaled, spike):
+@pytest.mark.parametrize("qscaled", [0, 4, 4 | 8, 4 | 8 | 16])
+@pytest.mark.parametrize("spike", [6.0, 30.0, 60.0])
+@pytest.mark.parametrize("spike_key", [200, 204, 70])
+def test_attention_online_softmax_rescale_branch(split, qscaled, spike, spike_key):
     """Force the running max to jump at a late key tile (spike one key against every query); with pre-scaled q the maximum lives
     inside the MFMA accumulator and the jump shifts the tile's scores, the running sums and the start vector.  spike 30: the
     jump is ~140 log2 units for the aligned query (exp2 against the old reference overflows to inf: the pipelined kernel's rare
@@ -550,7 +552,9 @@ def test_attention_online_softmax_rescale_branch(split, qscaled, spike):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(plan.total_rows, ld, generator=g) * 0.5
     q = x[:, :d].view(-1, 4, 64)
-    x[200, 2 * d: 2 * d + gq] = spike * torch.sign(q[5, 0]).repeat(2)   # key 200 (4th tile) dominates
+    # the spiked key dominates: 200 = 4th tile, held by the LOWER lane half of a query's lane pair; 204 by the UPPER half (the
+    # row maximum must cross the halves: round 5 found it did not); 70 = the first tile behind the reference
+    x[spike_key, 2 * d: 2 * d + gq] = spike * torch.sign(q[5, 0]).repeat(2)
     q_f32 = x[:, :d].clone()
     x = x.to(torch.bfloat16)
     out = torch.empty(plan.total_rows, d, dtype=torch.bfloat16, device=DEV)
@@ -560,6 +564,40 @@ def test_attention_online_softmax_rescale_branch(split, qscaled, spike):
     tab = plan.attention_table(hq, hkv, split)
     _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(),
                                  tab.shape[0], hq, hkv, 64, qscaled, _lib.TTV_BF16, S()), "attention")
+    f = x.float()
+    qq, gt, k, v = f.split([d, d, gq, gq], dim=-1)
+    ref = O.attention_varlen(qq.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)
+    assert_close(out.float(), ref, "bf16", scale=2.0)
+
+
+@pytest.mark.parametrize("spike", [6.0, 30.0, 60.0])
+@pytest.mark.parametrize("spike_keys", [(200,), (70,), (264,), (70, 130), (3,)])
+def test_attention_swp_reference_shift_branch(spike, spike_keys):
+    """k_attn_swp (ttv_attn_swp.hip) keeps the maximum of a row's first 64 scores as its softmax reference and checks only a tile's row
+    sums; a tile whose sums leave [0, 2^30] sends the wave through the rare path (true maximum of the tile's raw scores - still in
+    registers -, shift of O, l, both score sets in flight and the -m start vector, the tile's P again).  Forced here by spiking keys
+    against one query direction: in a middle tile (200), in the first tile behind the reference (70: the check of iteration 1), in the
+    masked last tile (264 of 265: the shift meets -inf scores), in two consecutive tiles (70 and 130, the second higher: the shifted
+    next score set is shifted again), and inside the first tile (3: no shift at all, the reference already holds it).  spike 30 / 60:
+    exp2 against the old reference overflows to inf for the aligned query (row sum inf or NaN), tens of log2 units for the others;
+    6: below 2^30 for most rows - the branch is wave-uniform, rows that did not need it shift by 0."""
+    plan = BatchPlan([(16, 64, 64)], [9], (4, 8, 8), DEV)  # S = 265 -> 5 key tiles, the last with 9 keys
+    hq, hkv, d, gq = 4, 2, 256, 128
+    ld = 2 * d + 2 * gq
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(plan.total_rows, ld, generator=g) * 0.5
+    q = x[:, :d].view(-1, 4, 64)
+    for n, key in enumerate(spike_keys):
+        x[key, 2 * d: 2 * d + gq] = (spike + 8.0 * n) * torch.sign(q[5, 0]).repeat(2)
+    x[140, :64] = q[5, 0]                 # the same direction for a query of another wave and block
+    q_f32 = x[:, :d].clone()
+    x = x.to(torch.bfloat16)
+    out = torch.full((plan.total_rows, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    xd = x.to(DEV)
+    xd[:, :d] = (q_f32 * (0.125 * 1.4426950408889634)).to(torch.bfloat16).to(DEV)
+    tab = plan.attention_table(hq, hkv, False)
+    _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(), tab.shape[0], hq, hkv, 64, 4 | 8,
+                                 _lib.TTV_BF16, S()), "attention")
     f = x.float()
     qq, gt, k, v = f.split([d, d, gq, gq], dim=-1)
     ref = O.attention_varlen(qq.unflatten(-1, (hq, 64)), k.unflatten(-1, (hkv, 64)), v.unflatten(-1, (hkv, 64)), plan.cu_seqlens).flatten(-2)
@@ -599,7 +637,7 @@ def test_attention64_varlen_gqa_gate(case, heads):
 
 
 @pytest.mark.parametrize("spike", [6.0, 30.0])
-@pytest.mark.parametrize("spike_key", [200, 20, 264])
+@pytest.mark.parametrize("spike_key", [200, 204, 20, 264])
 def test_attention64_reference_shift_branch(spike, spike_key):
     """Force the softmax reference of ttv_attention64 to move at a chosen key tile (one key spiked against one query direction): the
     wave-uniform shift of scores, row sum, O (accumulation registers) and the -m start vector, for tile A and tile B rows, in the

@@ -372,7 +372,11 @@ __global__ __launch_bounds__(256 * NE, NE == 2 ? 4 : 3) void k_attn_bf16(const b
       }
       const float m2 = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
       const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2), __builtin_bit_cast(unsigned, m2), false, false);
-      return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+      // (elements through named unsigneds: __builtin_bit_cast applied to the subscript of the builtin's vector result reads element 0
+      // for BOTH - hipcc 7.2 - and the maximum silently became the lower lane half's alone: found in round 5 by spiking keys of the
+      // upper half, test_attention_swp_reference_shift_branch / test_attention_online_softmax_rescale_branch)
+      const unsigned u0 = sw[0], u1 = sw[1];
+      return fmaxf(__uint_as_float(u0), __uint_as_float(u1));
     };
     // PRE: move the running reference up to the tile's maximum mx (relative to the current reference): scores, sums, O and the start
     // vector of the score accumulators shift with it
@@ -964,7 +968,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_pipe(const bf16_t* __restrict__
     b__ = fmaxf(fmaxf(b__, c_[13]), c_[14]);                                                                     \
     const float m2__ = fmaxf(fmaxf(a__, c_[7]), fmaxf(b__, c_[15]));                                             \
     const auto sw__ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2__), __builtin_bit_cast(unsigned, m2__), false, false); \
-    fmaxf(__builtin_bit_cast(float, sw__[0]), __builtin_bit_cast(float, sw__[1]));                               \
+    const unsigned u0__ = sw__[0], u1__ = sw__[1];     /* not __builtin_bit_cast(float, sw__[1]): see k_attn_bf16's row_max */ \
+    fmaxf(__uint_as_float(u0__), __uint_as_float(u1__));                                                         \
   })
   // in place p = exp2(s - m) of elements 8 SP_ .. 8 SP_ + 7 of a score set, their sum added to acc_ (two partial sums), and P as
   // a bf16 B fragment -> pa_
@@ -1676,6 +1681,11 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
     TTV_CHECK_ARG(!tape || !prescaled, "attention: the training-tape outputs need unscaled q");
     // tables of full items only with pre-scaled q, no tape: the software-pipelined kernel on request (flag TTV_ATTN_PIPE; slower
     // than the plain loop, see its header)
+    // round 5: the in-wave software pipeline of ttv_attn_swp.hip is the default for such tables (TTV_ATTN_SWP=0: k_attn_bf16, A/B)
+    static const bool swp_env = !(getenv("TTV_ATTN_SWP") && getenv("TTV_ATTN_SWP")[0] == '0');
+    if (swp_env && !(flags & TTV_ATTN_PIPE) && (flags & TTV_ATTN_ALLFULL) && prescaled && !paired && !tape && !(g_ttv_debug & 1048576)) {
+      return ttvk_attention_swp(qkvg, ld, out, ldo, cu_seqlens, qblocks, n_qblocks, q_heads, kv_heads, gate_mul, s);
+    }
     if ((flags & TTV_ATTN_PIPE) && (flags & TTV_ATTN_ALLFULL) && prescaled && !paired && !tape) {
       // the reference moves when a lane's 16-key sum of p exceeds 2^pipe_thr: bf16 P and fp32 sums have the range for it, and
       // with 40 the rare branch is rare for any score distribution (8, k_attn_bf16's value: every few tiles at a spread of 6)

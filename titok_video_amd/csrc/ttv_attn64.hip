@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_w64(const bf16_t* __restrict__ 
   ({                                                                                                             \
     const float m2__ = fmaxf(c0_, c1_);                                                                          \
     const auto sw__ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2__), __builtin_bit_cast(unsigned, m2__), false, false); \
-    fmaxf(__builtin_bit_cast(float, sw__[0]), __builtin_bit_cast(float, sw__[1]));                               \
+    const unsigned u0__ = sw__[0], u1__ = sw__[1];     /* not __builtin_bit_cast(float, sw__[1]): hipcc 7.2 reads element 0 for both */ \
+    fmaxf(__uint_as_float(u0__), __uint_as_float(u1__));                                                         \
   })
   // the tile's scores are relative to its running reference (they started from -m).  The reference moves only when some score of
   // the tile exceeds it by more than defer_thr (first tile: always, the reference is the placeholder 0): scores, row sum, O and

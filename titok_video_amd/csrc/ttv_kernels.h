@@ -103,6 +103,9 @@ int ttvk_attention(const void* qkvg, int ld, void* out, int ldo, const int* cu_s
                    int q_heads, int kv_heads, int head_dim, int flags, int dtype, hipStream_t s, float* lse_out = nullptr,
                    void* out_raw = nullptr);
 
+// bf16 tables of full items, pre-scaled q, no tape outputs: the software-pipelined kernel (ttv_attn_swp.hip); ttvk_attention dispatches
+int ttvk_attention_swp(const void* qkvg, int ld, void* out, int ldo, const int* cu_seqlens, const int* qblocks, int n_qblocks,
+                       int q_heads, int kv_heads, int gate_mul, hipStream_t s);
 int ttvk_attention_mxout(const void* qkvg, int ld, void* out_q, void* out_mx, int ld_mx, const int* cu_seqlens, const int* qblocks,
                          int n_qblocks, int q_heads, int kv_heads, hipStream_t s);
 

@@ -78,10 +78,13 @@ for spread in spreads:
     base[:, 2 * dm:2 * dm + g] *= a
     all_full = 8 if not bool((table[:, 3] > 0).any()) else 0
     variants = [(torch.bfloat16, "bf16 gate", 1, False), (torch.bfloat16, "bf16 gate+qscaled", 1 | 4, True)]
-    variants.append((torch.bfloat16, "bf16 gate+qscaled w64", 1 | 4 | W64, True))
+    if os.environ.get("W64", "0") == "1":
+        variants.append((torch.bfloat16, "bf16 gate+qscaled w64", 1 | 4 | W64, True))
     if all_full:
-        variants.append((torch.bfloat16, "bf16 gate+qscaled pipe", 1 | 4 | 8 | 16, True))
-    if os.environ.get("FP32", "1") == "1":
+        variants.append((torch.bfloat16, "bf16 gate+qscaled swp", 1 | 4 | 8, True))        # k_attn_swp (round 5, the default for such tables)
+        if os.environ.get("PIPE", "0") == "1":
+            variants.append((torch.bfloat16, "bf16 gate+qscaled pipe", 1 | 4 | 8 | 16, True))
+    if os.environ.get("FP32", "0") == "1":
         variants.append((torch.float32, "fp32 gate", 1, False))
     for dtype, name, flags, pre in variants:
         x = base.clone()
