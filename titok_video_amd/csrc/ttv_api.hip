@@ -119,9 +119,11 @@ static int run_layer_mx(const ttv_tower_dims* d, const ttv_layer_weights& lw, co
     TTV_TRY(ttvk_attention_mxout(ws.qkv, nq, ws.f8, ws.f8mx, (int)ttvk_mx_scale_ld(dm), b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads,
                                  d->kv_heads, s));
   } else {
+    // (no TTV_ATTN_ALLFULL unless the pipelined kernel is asked for: this is the A/B twin of the attention kernel with the fused MX
+    // epilogue above, which is k_attn_bf16 - the two must produce the same bits, tested)
     TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks, b->n_qblocks, d->q_heads, d->kv_heads, d->head_dim,
                            TTV_ATTN_GATE | (b->qblocks_paired ? TTV_ATTN_PAIRED : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) |
-                               (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
+                               ((b->qblocks_all_full && attn_pipe) ? TTV_ATTN_ALLFULL : 0) | (attn_pipe ? TTV_ATTN_PIPE : 0), dt, s));
     TTV_TRY(ttvk_quant_mx_fp8(ws.ao, dt, dm, ws.f8, dm, ws.f8mx, nullptr, L, dm, s));
   }
   GemmArgs o = {};
@@ -245,8 +247,10 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
     qkv_ready = false;
     const bool lat_now = lat_last && i == d->layers - 1;
     if (lat_now)
+      // (the latent table holds full items only; it is declared so only when the batch's own table is too: ttvk_attention picks its
+      // kernel by that flag, and the latent-rows forward must run the kernel the all-rows forward runs - same bits, tested)
       TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks_latent, b->n_qblocks_latent, d->q_heads, d->kv_heads, d->head_dim,
-                             TTV_ATTN_GATE | TTV_ATTN_ALLFULL | (q_scaled ? TTV_ATTN_QSCALED : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
+                             TTV_ATTN_GATE | (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
                                  (s3img ? (TTV_ATTN_SPLIT_OUT | TTV_ATTN_SPLIT_IN) : 0), dt, s));
     else if (q_scaled && b->items64 && b->n_items64 > 0 && d->head_dim == 64)
       TTV_TRY(ttvk_attention64(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->items64, b->n_items64, d->q_heads, d->kv_heads,

@@ -75,6 +75,48 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- lane exchanges on the vector ALU (gfx950 v_permlane16_swap / v_permlane32_swap) --------------------------------------------
+// hipcc lowers __shfl_xor(v, 16 | 32, 64) to index arithmetic + ds_bpermute_b32 + s_waitcnt lgkmcnt(0): an LDS round trip per
+// exchange, serialised by its wait.  The swaps below are single VALU instructions.  (Results are read through named unsigneds:
+// __builtin_bit_cast applied to a subscript of the builtin's vector result reads element 0 for both - hipcc 7.2.)
+// sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (same association as ss += shfl_xor(ss, 16); ss += shfl_xor(ss, 32))
+__device__ __forceinline__ float quad16_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // rows (r0, r0, r2, r2) | (r1, r1, r3, r3)
+  const unsigned a0 = a[0], a1 = a[1];
+  const float s = __uint_as_float(a0) + __uint_as_float(a1);
+  const unsigned t = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(t, t, false, false);      // halves (lo, lo) | (hi, hi)
+  const unsigned b0 = b[0], b1 = b[1];
+  return __uint_as_float(b0) + __uint_as_float(b1);
+}
+__device__ __forceinline__ float quad16_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const float s = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+  const unsigned t = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return fmaxf(__uint_as_float(b0), __uint_as_float(b1));
+}
+// sum over the two lanes l, l ^ 32
+__device__ __forceinline__ float pair32_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return __uint_as_float(b0) + __uint_as_float(b1);
+}
+// Lanes l and l ^ 16 (16-lane rows 2k and 2k + 1) each hold two 8-byte groups (p0, p1) of a row of which the even lane stores
+// (own p0, partner's p0) and the odd lane (partner's p1, own p1) as one 16-byte vector: v_permlane16_swap(vdst = p0, src = p1)
+// leaves exactly that pair in (vdst, src) for both.
+__device__ __forceinline__ uint4 xchg16_pair(uint2 p0, uint2 p1) {
+  const auto x = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+  const auto y = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+  const unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+  return make_uint4(x0, y0, x1, y1);
+}
+
 // ---- optional HIP-event bracketing of one kernel class (ttv_prof_begin / ttv_prof_end) ----------------
 extern int g_ttv_prof_class;
 extern thread_local int g_ttv_debug;

@@ -228,11 +228,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const uint2 p0 = pack_bf16x4(acc[i0][j]), p1 = pack_bf16x4(acc[i1][j]);
-        const uint2 send = odd ? p0 : p1;
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 16, 64);
-        recv.y = __shfl_xor(send.y, 16, 64);
-        const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        const uint4 out = xchg16_pair(p0, p1);     // v_permlane16_swap: even kq (own p0, partner's p0), odd kq (partner's p1, own p1)
         const int start = odd ? feat[i1] - 4 : feat[i0];
         if (EPI == EPI_STORE_PATCH) {
           // 8 consecutive features = the pw = 8 pixels of one (c, ipt, iph) image row of the patch (utils.py:37-51, patch
@@ -1076,8 +1072,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp8_dma(GemmDev p, int n_ftiles
         }
         float a = fmaxf(fmaxf(fmaxf(fabsf(h0[0]), fabsf(h0[1])), fmaxf(fabsf(h0[2]), fabsf(h0[3]))),
                         fmaxf(fmaxf(fabsf(h1[0]), fabsf(h1[1])), fmaxf(fabsf(h1[2]), fabsf(h1[3]))));
-        a = fmaxf(a, __shfl_xor(a, 16, 64));
-        a = fmaxf(a, __shfl_xor(a, 32, 64));
+        a = quad16_max(a);
         const uint32_t tb = __float_as_uint(a * (1.0f / 448.0f));
         int byte = (int)((tb >> 23) & 0xFF) + ((tb & 0x7FFFFF) ? 1 : 0);
         byte = a > 0.f ? (byte < 1 ? 1 : (byte > 254 ? 254 : byte)) : 127;
@@ -1286,8 +1281,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(GemmDev p, int n_panels, i
               const float v = (float)bfr[j][s8][e];
               ss = fmaf(v, v, ss);
             }
-          ss += __shfl_xor(ss, 16, 64);
-          ss += __shfl_xor(ss, 32, 64);
+          ss = quad16_sum(ss);
           rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
         }
       }
@@ -1457,8 +1451,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_t
 #pragma unroll
       for (int e = 0; e < 4; ++e) ss = fmaf(acc[i][e], acc[i][e], ss);
     }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    ss = quad16_sum(ss);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
     const bool odd = kq & 1;
     bf16_t* yrow = (bf16_t*)p.y + (size_t)t * p.ldy;
@@ -1481,17 +1474,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_t
     for (int ip = 0; ip < 8; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       const uint2 p0 = pack_bf16x4(acc[i0]), p1 = pack_bf16x4(acc[i1]);
-      const uint2 send = odd ? p0 : p1;
-      uint2 recv;
-      recv.x = __shfl_xor(send.x, 16, 64);
-      recv.y = __shfl_xor(send.y, 16, 64);
-      const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+      const uint4 out = xchg16_pair(p0, p1);     // v_permlane16_swap: even kq (own p0, partner's p0), odd kq (partner's p1, own p1)
       const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
       if (tvalid && !(p.debug & 1)) *reinterpret_cast<uint4*>(yrow + start) = out;
     }
     if (p.y2) {                         // the NEXT pre-norm of the row just written (training tape: xn of the following sub-layer)
-      ss2 += __shfl_xor(ss2, 16, 64);
-      ss2 += __shfl_xor(ss2, 32, 64);
+      ss2 = quad16_sum(ss2);
       const float rstd2 = 1.0f / sqrtf(ss2 * (1.0f / 256.0f) + p.eps);
       bf16_t* y2row = (bf16_t*)p.y2 + (size_t)t * p.ldy2;
 #pragma unroll
@@ -1503,11 +1491,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256_rownorm(GemmDev p, int n_t
 #pragma unroll
         for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][e] * rstd2 * g0[e]; y1[e] = acc[i1][e] * rstd2 * g1[e]; }
         const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
-        const uint2 send = odd ? p0 : p1;
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 16, 64);
-        recv.y = __shfl_xor(send.y, 16, 64);
-        const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        const uint4 out = xchg16_pair(p0, p1);     // v_permlane16_swap: even kq (own p0, partner's p0), odd kq (partner's p1, own p1)
         const int start = odd ? i1 * 16 + kq * 4 - 4 : i0 * 16 + kq * 4;
         if (tvalid && !(p.debug & 1)) *reinterpret_cast<uint4*>(y2row + start) = out;
       }
@@ -1617,8 +1601,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) ss = fmaf(acc[i][j][e], acc[i][j][e], ss);
     }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    ss = quad16_sum(ss);
     ssq[j] = ss;
   }
   if (kq == 0) {
@@ -1647,19 +1630,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
         ss2 = fmaf(acc[i][j][e], acc[i][j][e], ss2);
       }
     }
-    ss2 += __shfl_xor(ss2, 16, 64);
-    ss2 += __shfl_xor(ss2, 32, 64);
+    ss2 = quad16_sum(ss2);
     ssq2[j] = ss2;
 #pragma unroll
     for (int ip = 0; ip < 2; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       const int f0 = wave * 64 + i0 * 16 + kq * 4, f1 = wave * 64 + i1 * 16 + kq * 4;
       const uint2 p0 = pack_bf16x4(acc[i0][j]), p1 = pack_bf16x4(acc[i1][j]);
-      const uint2 send = odd ? p0 : p1;
-      uint2 recv;
-      recv.x = __shfl_xor(send.x, 16, 64);
-      recv.y = __shfl_xor(send.y, 16, 64);
-      const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+      const uint4 out = xchg16_pair(p0, p1);     // v_permlane16_swap: even kq (own p0, partner's p0), odd kq (partner's p1, own p1)
       const int start = odd ? f1 - 4 : f0;
       if (t < p.M && !(p.debug & 1)) *reinterpret_cast<uint4*>((bf16_t*)p.y + (size_t)t * p.ldy + start) = out;
     }
@@ -1685,11 +1663,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rowtile_norm(GemmDev p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { y0[e] = acc[i0][j][e] * rstd2 * g0[e]; y1[e] = acc[i1][j][e] * rstd2 * g1[e]; }
         const uint2 p0 = pack_bf16x4(y0), p1 = pack_bf16x4(y1);
-        const uint2 send = odd ? p0 : p1;
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 16, 64);
-        recv.y = __shfl_xor(send.y, 16, 64);
-        const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        const uint4 out = xchg16_pair(p0, p1);     // v_permlane16_swap: even kq (own p0, partner's p0), odd kq (partner's p1, own p1)
         const int start = odd ? f1 - 4 : f0;
         if (t < p.M && !(p.debug & 1)) *reinterpret_cast<uint4*>((bf16_t*)p.y2 + (size_t)t * p.ldy2 + start) = out;
       }

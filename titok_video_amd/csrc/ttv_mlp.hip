@@ -260,8 +260,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
       }
       float scale = 1.0f;
       if (p.front_gain) {
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = quad16_sum(ss);
         scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
       }
       float ss2 = 0.f;
@@ -286,8 +285,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
         }
         bfr[j][s8] = (bf16x8){q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3]};
       }
-      ss2 += __shfl_xor(ss2, 16, 64);
-      ss2 += __shfl_xor(ss2, 32, 64);
+      ss2 = quad16_sum(ss2);
       rstd[j] = 1.0f / sqrtf(ss2 * (1.0f / 256.0f) + p.eps);
     }
   } else {
@@ -315,8 +313,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
           const float v = (float)bfr[j][s8][e];
           ss = fmaf(v, v, ss);
         }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
+      ss = quad16_sum(ss);
       rstd[j] = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
     }
   }
@@ -488,8 +485,7 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
     }
     float scale = 1.0f;
     if (KEEL) {
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
+      ss = quad16_sum(ss);
       scale = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
     }
     const bool odd = kq & 1;
@@ -517,16 +513,11 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
           ssq = fmaf(r1, r1, ssq);
         }
       }
-      const uint2 send = odd ? p0 : p1;
-      uint2 recv;
-      recv.x = __shfl_xor(send.x, 16, 64);
-      recv.y = __shfl_xor(send.y, 16, 64);
-      const uint4 ov = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+      const uint4 ov = xchg16_pair(p0, p1);     // even kq: (own p0, partner's p0), odd kq: (partner's p1, own p1) - one VALU op per dword
       if (tv && !(p.debug & 1)) *(__attribute__((address_space(1))) u32x4_t*)(gy + yoff + ip * 64) = (u32x4_t){ov.x, ov.y, ov.z, ov.w};
     }
     if (BACK) {
-      ssq += __shfl_xor(ssq, 16, 64);
-      ssq += __shfl_xor(ssq, 32, 64);
+      ssq = quad16_sum(ssq);
       rstdq[j] = 1.0f / sqrtf(ssq * (1.0f / 256.0f) + p.eps);
     }
   }
@@ -611,11 +602,8 @@ __device__ __forceinline__ void mlp_wave(const MlpDev& p, uint4* l12, uint4* l3,
             const bf16x4 q = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
             pk[u] = __builtin_bit_cast(uint2, q);
           }
-          const uint2 send = odd ? pk[0] : pk[1];
-          uint2 recv;
-          recv.x = __shfl_xor(send.x, 16, 64);
-          recv.y = __shfl_xor(send.y, 16, 64);
-          const u32x4_t ov = odd ? (u32x4_t){recv.x, recv.y, pk[1].x, pk[1].y} : (u32x4_t){pk[0].x, pk[0].y, recv.x, recv.y};
+          const uint4 ox = xchg16_pair(pk[0], pk[1]);
+          const u32x4_t ov = {ox.x, ox.y, ox.z, ox.w};
           if (qv[j]) *(__attribute__((address_space(1))) u32x4_t*)(qrow + ip * 64) = ov;
         }
       }

@@ -72,6 +72,8 @@ print(f"shape: {B} x {S} rows, {HQ}/{HKV} heads, table {table.shape[0]} entries 
 for spread in spreads:
     gen = torch.Generator(device="cpu").manual_seed(7)
     base = torch.randn(L, ld, generator=gen)
+    if os.environ.get("ZERO", "0") == "1":      # clock probe: all-zero operands draw less power, the part holds a higher clock (rule 25)
+        base.zero_()
     # score exponent std = |q||k| terms: q, k ~ N(0, a^2) -> q.k std = 8 a^2; exponent = q.k * C_EXP
     a = math.sqrt(spread / (8.0 * C_EXP))
     base[:, :dm] *= a
