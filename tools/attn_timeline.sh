@@ -4,5 +4,5 @@ set -e
 cd "$(dirname "$0")/../titok_video_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vectorize -Wall -Wno-unused-function"
 hipcc $FLAGS -DATTN_TIMELINE -c ttv_attn.hip -o build/ttv_attn_timeline.o
-hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o build/ttv_gemm.o build/ttv_attn_timeline.o build/ttv_attn64.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o build/libtitok_hip_timeline.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o build/ttv_gemm.o build/ttv_attn_timeline.o build/ttv_attn_swp.o build/ttv_attn64.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o build/libtitok_hip_timeline.so
 echo "built $(realpath build/libtitok_hip_timeline.so)"

@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vectorize -Wno-unused-function -Wno-unused-variable"
   for n in $NAMES; do
     ( hipcc $FLAGS $(flags $n) -c ttv_gemm.hip -o $V/gemm_$n.o 2> $V/gemm_$n.log &&
-      hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o $V/gemm_$n.o build/ttv_attn.o build/ttv_attn64.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o $V/libtitok_hip_qw_$n.so && rm $V/gemm_$n.o ) &
+      hipcc --offload-arch=gfx950 -shared -fPIC build/ttv_elem.o $V/gemm_$n.o build/ttv_attn.o build/ttv_attn_swp.o build/ttv_attn64.o build/ttv_mlp.o build/ttv_bwd.o build/ttv_train.o build/ttv_vq.o build/ttv_api.o -o $V/libtitok_hip_qw_$n.so && rm $V/gemm_$n.o ) &
     [ $(jobs -r | wc -l) -ge 4 ] && wait -n
   done
   wait; ls -la $V/*.so
