@@ -353,6 +353,13 @@ typedef struct ttv_batch {
    * never computed.  Ignored by the decoder and by the training entry points. */
   const int32_t* qblocks_latent;
   int32_t n_qblocks_latent;
+  /* optional (NULL / 0: off), the decoder-side twin: an attention work table (format of `qblocks`, full items only) without the query
+   * blocks that hold latent rows ONLY (block q of a sequence with (q + 1) * 128 <= K_b).  The decoder's output is read from its patch
+   * rows alone (blocks.py:171), so with this table ttv_decoder_forward runs the LAST layer's attention without those blocks: the rows
+   * it skips keep the previous layer's attention output, everything behind the attention is row-wise, and no patch row changes a bit.
+   * Ignored by the encoder and by the training entry points. */
+  const int32_t* qblocks_patch;
+  int32_t n_qblocks_patch;
 } ttv_batch;
 
 /* Fill ttv_batch.rope_cs [L,64] on the device: rows are gathered from base_cos/base_sin fp32 [n_ids, n_freqs] =

@@ -46,8 +46,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.LayerWeights) == 25 * 8   # 24 pointers (8 of them the MX fp8 images, round 4) + int32 mlp_pack_qkv_rows + int32 qkv_q_prescaled
     assert C.sizeof(_lib.TowerWeights) == 11 * 8   # 10 pointers + int32 f32_split3 (padded)
     # + blocks64, row_seq, n_blocks64, qblocks_paired, qblocks_all_full (+ pad), items64, n_items64 (+ pad), rope_ids, rope_base,
-    # qblocks_latent, n_qblocks_latent (+ pad)
-    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 16 + 8 + 8 + 16 + 16
+    # qblocks_latent, n_qblocks_latent (+ pad), qblocks_patch, n_qblocks_patch (+ pad)
+    assert C.sizeof(_lib.Batch) == 6 * 4 + 8 * 8 + 16 + 8 + 8 + 16 + 16 + 16
     src = open(HEADER).read()
     for struct, cls in [("ttv_fsq_params", _lib.FsqParams), ("ttv_tower_dims", _lib.TowerDims),
                         ("ttv_layer_weights", _lib.LayerWeights), ("ttv_tower_weights", _lib.TowerWeights),

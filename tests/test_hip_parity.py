@@ -289,6 +289,40 @@ def test_encoder_last_layer_on_latent_rows_only_changes_no_bit(mode):
     assert torch.equal(outs[0][0], outs[1][0]), "codes differ"
 
 
+def test_decoder_last_layer_without_latent_only_query_blocks_changes_no_bit(monkeypatch):
+    """The decoder's output is read from its patch rows (blocks.py:171).  With `ttv_batch.qblocks_patch` the last layer's attention
+    skips the 128-row query blocks that hold latent rows only; everything behind the attention is row-wise and the tail gathers patch
+    rows, so the reconstructions are the bits of the all-blocks forward (ttv_debug_set bit 21 switches the shortcut off).  Token counts
+    of one block exactly (128: block 0 skipped), more than one block (200: block 0 skipped, block 1 mixed), and less than one (17:
+    nothing to skip)."""
+    from titok_video_amd import _lib
+    from titok_video_amd.plan import BatchPlan
+    monkeypatch.setenv("TTV_ATTN_SPLIT", "0")        # full items at this small batch too (the shortcut is for tables of full items)
+    model = build(torch.bfloat16)
+    shapes = [(16, 128, 128), (16, 128, 128), (16, 64, 64), (8, 32, 48)]
+    counts = [128, 200, 17, 128]
+    plan = BatchPlan(shapes, counts, (4, 8, 8), torch.device(DEV))
+    full, part = plan.attention_table(4, 2), plan.attention_table_patch(4, 2)
+    n = lambda t: int((t[:, 0] >= 0).sum())
+    assert part is not None and n(part) == n(full) - 4 * (1 + 1 + 0 + 1)      # one latent-only block per clip with K >= 128, 4 q-heads
+    clips = synthetic_clips(shapes, seed=33, dtype=torch.bfloat16, device=DEV)
+    lib = _lib.lib()
+    with torch.no_grad():
+        codes, info = model.encode(clips, counts)
+    outs = []
+    try:
+        for bits in (0, 1 << 21):
+            lib.ttv_debug_set(bits)
+            with torch.no_grad():
+                recon = model.decode(codes, counts, shapes)
+            torch.cuda.synchronize()
+            outs.append([r.clone() for r in recon])
+    finally:
+        lib.ttv_debug_set(0)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "reconstructions differ"
+    assert all(torch.isfinite(a.float()).all() for a in outs[0])
+
+
 def test_more_clips_than_one_pointer_table_bf16():
     """Batches of more than TTV_MAX_CLIPS_PER_LAUNCH (64) clips take the stand-alone patch copy / ln_post kernels instead of
     the GEMM-fused gather / scatter: same results up to bf16 rounding of the folded gain."""

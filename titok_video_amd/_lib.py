@@ -59,7 +59,8 @@ class Batch(C.Structure):
                 ("max_patches_per_clip", i32), ("n_qblocks", i32), ("cu_seqlens", vp), ("latent_rows", vp),
                 ("patch_rows", vp), ("clip_desc", vp), ("qblocks", vp), ("rope_cs", vp), ("blocks64", vp), ("row_seq", vp),
                 ("n_blocks64", i32), ("qblocks_paired", i32), ("qblocks_all_full", i32), ("items64", vp), ("n_items64", i32),
-                ("rope_ids", vp), ("rope_base", vp), ("qblocks_latent", vp), ("n_qblocks_latent", i32)]
+                ("rope_ids", vp), ("rope_base", vp), ("qblocks_latent", vp), ("n_qblocks_latent", i32), ("qblocks_patch", vp),
+                ("n_qblocks_patch", i32)]
 
 
 class LayerWeightsT(C.Structure):

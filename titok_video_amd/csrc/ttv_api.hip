@@ -194,6 +194,12 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
   static const bool lat_env = !(getenv("TTV_ENC_LATENT_LAST") && getenv("TTV_ENC_LATENT_LAST")[0] == '0');
   const bool lat_last = lat_env && !(g_ttv_debug & 524288) && d->kind == TTV_ENCODER && b->qblocks_latent && b->n_qblocks_latent > 0 &&
                         b->latent_rows && b->sum_tokens > 0 && b->sum_tokens < L;
+  // The decoder's output is its patch rows (blocks.py:171): with the batch's patch-query table the LAST layer's attention skips the query
+  // blocks that hold latent rows only.  Their rows of ws.ao keep the previous layer's values (finite), everything behind the attention
+  // is row-wise, the tail gathers patch rows: no patch row changes a bit.  TTV_DEC_PATCH_LAST=0 / debug bit 21: every block (A/B, tests).
+  static const bool pat_env = !(getenv("TTV_DEC_PATCH_LAST") && getenv("TTV_DEC_PATCH_LAST")[0] == '0');
+  const bool pat_last = pat_env && !(g_ttv_debug & 2097152) && d->kind == TTV_DECODER && d->layers >= 2 && b->qblocks_patch &&
+                        b->n_qblocks_patch > 0 && !split3 && !b->qblocks_paired;
   bool compacted = false;
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
@@ -252,6 +258,9 @@ static int run_layers(const ttv_tower_dims* d, const ttv_tower_weights* w, const
       TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks_latent, b->n_qblocks_latent, d->q_heads, d->kv_heads, d->head_dim,
                              TTV_ATTN_GATE | (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0) | (split3 ? TTV_ATTN_SPLIT3 : 0) |
                                  (s3img ? (TTV_ATTN_SPLIT_OUT | TTV_ATTN_SPLIT_IN) : 0), dt, s));
+    else if (pat_last && i == d->layers - 1 && dt == TTV_BF16 && !attn_pipe)
+      TTV_TRY(ttvk_attention(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->qblocks_patch, b->n_qblocks_patch, d->q_heads, d->kv_heads, d->head_dim,
+                             TTV_ATTN_GATE | (b->qblocks_all_full ? TTV_ATTN_ALLFULL : 0) | (q_scaled ? TTV_ATTN_QSCALED : 0), dt, s));
     else if (q_scaled && b->items64 && b->n_items64 > 0 && d->head_dim == 64)
       TTV_TRY(ttvk_attention64(ws.qkv, nq, ws.ao, dm, b->cu_seqlens, b->items64, b->n_items64, d->q_heads, d->kv_heads,
                                TTV_ATTN_GATE | TTV_ATTN_QSCALED, s));

@@ -349,6 +349,41 @@ class BatchPlan:
             self._attn[key] = t
         return t
 
+    def attention_table_patch(self, q_heads: int, kv_heads: int) -> Optional[torch.Tensor]:
+        """int32 [n,4] attention work table like `attention_table` (full items only) WITHOUT the query blocks that hold latent rows only
+        (block q of sequence b with (q + 1) * 128 <= K_b), or None when no sequence has such a block.  The decoder reads its output from
+        the patch rows alone (reference blocks.py:171), so its last layer needs no attention output for those query rows
+        (`ttv_batch.qblocks_patch`): at the benchmark shape 1024 entries instead of 1152.  Same XCD interleaving as the full table."""
+        key = ("patch", int(q_heads), int(kv_heads))
+        if key not in self._attn:
+            rep = q_heads // kv_heads
+            units, dropped = [], 0
+            for b in range(len(self.grids)):
+                s = self.cu_seqlens[b + 1] - self.cu_seqlens[b]
+                nq = -(-s // QBLOCK)
+                first = int(self.token_counts[b]) // QBLOCK          # blocks [0, first) hold latent rows only
+                dropped += first
+                for kvh in range(kv_heads):
+                    units.append([(b, qb * QBLOCK, kvh * rep + r, 0) for qb in range(first, nq) for r in range(rep)])
+            t = None
+            if dropped and any(units):
+                order = sorted(range(len(units)), key=lambda i: len(units[i]), reverse=True)
+                lists, weight = [[] for _ in range(8)], [0] * 8
+                for i in order:
+                    x = min(range(8), key=lambda j: weight[j])
+                    lists[x].extend(units[i])
+                    weight[x] += len(units[i])
+                depth = max(len(l) for l in lists)
+                table = np.full((depth, 8, 4), -1, dtype=np.int32)
+                for x, l in enumerate(lists):
+                    if l:
+                        table[: len(l), x, :] = np.asarray(l, dtype=np.int32)
+                flat = table.reshape(-1, 4)
+                last = int(np.max(np.nonzero(flat[:, 0] >= 0)[0])) + 1
+                t = _upload(np.ascontiguousarray(flat[:last]), self.device)
+            self._attn[key] = t
+        return self._attn[key]
+
     def attention_table64(self, q_heads: int, kv_heads: int) -> torch.Tensor:
         """int32 [n,8] work table of ttv_attention64 (the 64-query-rows-per-wave kernel): one entry per workgroup =
         (sequence, kv-head, 4 x wave item, first packed row of the sequence, its length); a wave item is
@@ -405,9 +440,13 @@ class BatchPlan:
         t64 = self.attention_table64(q_heads, kv_heads) if (q_heads <= 255 and os.environ.get("TTV_ATTN64", "0") == "1") else None
         # the encoder's last layer on its latent rows only (ttv_batch.qblocks_latent; TTV_ENC_LATENT_LAST=0 in the library: A/B)
         tl = self.attention_table_latent(q_heads, kv_heads) if sum(int(k) for k in self.token_counts) > 0 else None
+        # the decoder's last layer without the query blocks that hold latent rows only (ttv_batch.qblocks_patch; TTV_DEC_PATCH_LAST=0: A/B)
+        # (only beside a table of full items: the last layer must run the kernel, and the item kind, the all-blocks forward runs)
+        tp = self.attention_table_patch(q_heads, kv_heads) if all_full else None
         return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
                           items64=t64.data_ptr() if t64 is not None else None, n_items64=int(t64.shape[0]) if t64 is not None else 0,
                           qblocks_latent=tl.data_ptr() if tl is not None else None, n_qblocks_latent=int(tl.shape[0]) if tl is not None else 0,
+                          qblocks_patch=tp.data_ptr() if tp is not None else None, n_qblocks_patch=int(tp.shape[0]) if tp is not None else 0,
                           **self._base_fields)
 
     # views used by tests that call single ops

@@ -29,6 +29,26 @@ if [ $PART = r04 ]; then       # round 4 evidence set: the driver's command, bot
   MODE=fp32 timeout -k 10 300 python3 $R/tools/exact_index_bench.py > $O/exact_index_fp32.txt 2>&1
   find $O -name "*kernel_trace.csv" -delete
 fi
+if [ $PART = r05 ]; then       # round 5 evidence set: the driver's command, both modes under rocprof, traffic counters, attention alone + stamps + clock, power probe
+  step bench default; timeout -k 10 500 python3 $R/bench.py > $O/tiny_bench.json 2> $O/tiny_bench.err
+  step bench in-flight 1; timeout -k 10 300 python3 $R/bench.py --in-flight 1 --no-cpu-baseline --no-side-legs > $O/tiny_bench_inflight1.json 2>> $O/tiny_bench.err
+  step rocprof two chains; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -o p -- python3 $R/bench.py --no-cpu-baseline --no-fp32-leg --no-side-legs > $O/tiny_bench_under_rocprof.json 2> $O/prof_if2.log
+  step rocprof one chain; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -o p -- python3 $R/bench.py --in-flight 1 --no-cpu-baseline --no-fp32-leg --no-side-legs > $O/tiny_bench_inflight1_under_rocprof.json 2> $O/prof_if1.log
+  step pmc fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python3 $R/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-leg --no-side-legs > /dev/null 2> $O/pmc_f.log
+  step pmc write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python3 $R/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-leg --no-side-legs > /dev/null 2> $O/pmc_w.log
+  step attention alone; FP32=0 timeout -k 10 200 python3 $R/tools/attn_bench.py 1.5 6 > $O/attn_bench.txt 2>&1
+  for b in 48 64; do echo "== B=$b" >> $O/attn_bench.txt; B=$b timeout -k 10 200 python3 $R/tools/attn_bench.py 1.5 2>&1 | grep qscaled >> $O/attn_bench.txt; done
+  echo "== base shape" >> $O/attn_bench.txt; B=4 CLIP=32,256,256 K=1024 HQ=12 HKV=4 FP32=0 timeout -k 10 200 python3 $R/tools/attn_bench.py 1.5 >> $O/attn_bench.txt 2>&1
+  step stamps + clock; TTV_LIB_PATH=$R/titok_video_amd/csrc/build/libtitok_hip_swpstamps.so timeout -k 10 200 python3 $R/tools/swp_stamps.py > $O/swp_stamps.txt 2>&1
+  echo "== all-zero operands" >> $O/swp_stamps.txt; ZERO=1 TTV_LIB_PATH=$R/titok_video_amd/csrc/build/libtitok_hip_swpstamps.so timeout -k 10 200 python3 $R/tools/swp_stamps.py >> $O/swp_stamps.txt 2>&1
+  step power probe; timeout -k 10 200 python3 $R/tools/power_probe.py > $O/power_probe.txt 2>&1
+  for z in 0 1; do echo "== attn_bench B=64 ZERO=$z" >> $O/power_probe.txt; ZERO=$z B=64 timeout -k 10 200 python3 $R/tools/attn_bench.py 1.5 2>&1 | grep qscaled >> $O/power_probe.txt; done
+  for i in 1 2; do
+    case $i in 1) C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU";; 2) C="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA GRBM_GUI_ACTIVE";; esac
+    step sq pass $i: $C; FP32=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/sq$i -o s -- python3 $R/tools/attn_bench.py 1.5 > /dev/null 2> $O/sq$i.log
+  done
+  find $O -name "*kernel_trace.csv" -delete
+fi
 if [ $PART = r04base ]; then
   step base; timeout -k 10 300 python3 $R/bench.py --config base > $O/base_bench.json 2> $O/base_bench.err
   step base5; timeout -k 10 300 python3 $R/bench.py --config base5 > $O/base5_bench.json 2>> $O/base_bench.err

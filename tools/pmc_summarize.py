@@ -16,6 +16,7 @@ import json
 import os
 
 CLASS_OF = (            # kernel-name fragment -> bench.py --kernel class
+    ("k_attn_swp<", "attention"),     # round 5: the software-pipelined kernel (tables of full items, pre-scaled q)
     ("k_attn_bf16<", "attention"),
     ("k_qkv256<", "gemm_qkv"),        # round 4: the wave-pipelined to_qkv kernel (k_gemm_k256<1,..> before / with TTV_QKV256=0)
     ("k_gemm_k256<1,", "gemm_qkv"),
@@ -69,9 +70,10 @@ def main():
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); "
                         f"steady-state dispatches only (first {args.skip_first} per kernel dropped); source "
                         f"profiles/{args.tag}_pmc_*_per_kernel.csv. {args.note}".strip()}
-    for prefix, cls in CLASS_OF:
-        fk = [(n, v) for k, (n, v) in fetch.items() if prefix in k]
-        wk = [(n, v) for k, (n, v) in write.items() if prefix in k]
+    for cls in dict.fromkeys(c for _, c in CLASS_OF):          # a class may have several kernel names: one weighted average over all of them
+        prefixes = [pf for pf, c in CLASS_OF if c == cls]
+        fk = [(n, v) for k, (n, v) in fetch.items() if any(pf in k for pf in prefixes)]
+        wk = [(n, v) for k, (n, v) in write.items() if any(pf in k for pf in prefixes)]
         if not fk or not wk:
             continue
         fb = 2.0 * 1024.0 * sum(n * v for n, v in fk) / sum(n for n, _ in fk)
