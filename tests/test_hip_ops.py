@@ -604,6 +604,42 @@ def test_attention_swp_reference_shift_branch(spike, spike_keys):
     assert_close(out.float(), ref, "bf16", scale=2.0)
 
 
+@pytest.mark.parametrize("level", [-40.0, -100.0, 90.0])
+def test_attention_swp_rows_whose_scores_all_sit_far_from_zero(level):
+    """k_attn_swp exponentiates the scores as they stand (no softmax reference in its loop) and reads off the row sums whether that was in
+    range (2^-60 < l < 2^60); otherwise the block runs again through the exact loop.  Here EVERY score of some query rows is shifted by
+    `level` log2-units (the keys share a direction u, those queries are level * u / |u|^2 plus noise): -40 stays in range (p ~ 2^-40,
+    no fallback: the quotient must still be right), -100 underflows the row sums (l < 2^-60: fallback), +90 overflows them."""
+    plan = BatchPlan([(16, 64, 64)], [9], (4, 8, 8), DEV)  # S = 265
+    hq, hkv, d, gq = 4, 2, 256, 128
+    ld = 2 * d + 2 * gq
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(plan.total_rows, ld, generator=g) * 0.3
+    u = torch.randn(64, generator=g)
+    u = u / u.norm() * 4.0                                        # |u| = 4
+    x[:, 2 * d: 2 * d + gq] += u.repeat(2)                        # every key of both kv-heads carries u
+    c_exp = 0.125 * 1.4426950408889634
+    for row in (5, 77, 140, 264):                                  # queries of several waves / blocks, all four q-heads
+        x[row, :d] += (level / (c_exp * 16.0)) * u.repeat(4)      # q . u * c_exp = level
+    q_f32 = x[:, :d].clone()
+    x = x.to(torch.bfloat16)
+    out = torch.full((plan.total_rows, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    xd = x.to(DEV)
+    xd[:, :d] = (q_f32 * c_exp).to(torch.bfloat16).to(DEV)
+    tab = plan.attention_table(hq, hkv, False)
+    _lib.check(L().ttv_attention(xd.data_ptr(), ld, out.data_ptr(), d, plan.cu_dev.data_ptr(), tab.data_ptr(), tab.shape[0], hq, hkv, 64, 4 | 8,
+                                 _lib.TTV_BF16, S()), "attention")
+    # reference: float64 softmax attention on the operands the kernel sees - the PRE-SCALED q as rounded to bf16 (queries of magnitude
+    # ~17 round differently before and after the factor, which alone moves these peaked rows by ~1 %: tests/probes/swp_level_probe.py)
+    qs = xd[:, :d].double().cpu().view(-1, hq, 64)
+    kk, vv = x[:, 2 * d:2 * d + gq].double().view(-1, hkv, 64), x[:, 2 * d + gq:].double().view(-1, hkv, 64)
+    ref = torch.empty(plan.total_rows, d, dtype=torch.float64)
+    for hh in range(hq):
+        sc = qs[:, hh] @ kk[:, hh // (hq // hkv)].T * 0.6931471805599453
+        ref[:, hh * 64:(hh + 1) * 64] = torch.softmax(sc, -1) @ vv[:, hh // (hq // hkv)]
+    assert_close(out.float(), ref, "bf16", scale=2.0)
+
+
 @pytest.mark.parametrize("case", [([(4, 16, 16)], [1]), ([(8, 32, 48), (4, 8, 24), (16, 64, 64)], [5, 3, 128]),
                                   ([(16, 128, 128)], [128]), ([(4, 8, 8), (4, 8, 8)], [0, 63]), ([(16, 64, 64)] * 3, [0, 61, 128])])
 @pytest.mark.parametrize("heads", [(4, 2), (12, 4), (2, 2)])
