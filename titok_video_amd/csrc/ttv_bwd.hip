@@ -694,13 +694,79 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const bf16_t* __restrict__ d
 // block stores its 128 x 128 fp32 tile in fragment order (each wave instruction writes 1 KB contiguous) to
 // part[(tile * splits + split)][wave][i][j][lane][4]; k_wgrad_reduce sums the splits in a fixed order and adds into dW, so
 // the result is also bit-reproducible from run to run.
+// Round 5: loader waves.  A wave can issue one 1 KB global_load_lds_dwordx4 per ~105 - 140 cycles at best (tools/ubench/dma_rates.hip),
+// and the round-4 loop had every compute wave issue eight of them per 64-token stage in front of its 32 MFMAs (512 cycles): ~2 200
+// cycles per stage and block, two blocks per CU (a deeper ring alone changed nothing: profiles/r05_negative_results.txt).  Now a block
+// has 4 + WG_NL waves: waves 0-3 compute as before (64 x 64 outputs each; per 32-token sub-step 16 MFMAs with the 16 transposed
+// fragment reads of the NEXT sub-step under the first eight of them), the others only stage - loader w issues the instructions of
+// its 64 / WG_NL token rows of the stage WG_RING - 1 ahead, waits for the stage one ahead (counted: the younger stages stay in flight),
+// zeroes its rows past the token range and joins the block's one barrier per stage.  One block per CU (128 KB of ring), ~800 cycles
+// per stage on every CU instead of ~1 085 (2 170 / 2 blocks), and a lone block per CU - grids of fewer blocks than 2 per CU, which is
+// what the split plan produces - no longer runs at half speed: w12 57 -> 39 us, the others 30 - 34 -> 25 - 26 us, training step
+// 7.10 -> 6.97 ms (profiles/r05_wgrad_loader_waves.txt).  Measured on the way: 4 and 8 loader waves are equal (the ring is not what the
+// compute waves wait for); a 3-slot ring (one stage of lead) exposes the load latency (w12 58 us); operands re-read from L2 only are
+// no faster, so the remaining ~290 cycles per stage above the MFMAs are the block-wide barrier and its drain (tools/wgrad_stamps.py).
+// Same MFMA sequence per accumulator as before (a partial tile over the same token range has the round-4 kernel's bits; the split plan
+// - and with it the order of the fp32 sum over ranges - changed with the one-block-per-CU grid).
+#ifndef WG_RING
+#define WG_RING 4           // ring slots (3 or 4): the loaders run WG_RING - 2 stages ahead of the stage the compute waves prefetch from
+#endif
+#ifndef WG_NL
+#define WG_NL 4            // loader waves per block (4 or 8: equal speed)
+#endif
+#ifdef WG_L2TEST               // diagnostic build: every stage re-reads the block's first four (cache-resident operands; results wrong)
+#define WG_SRC_STAGE(s_) ((s_) & 3)
+#else
+#define WG_SRC_STAGE(s_) (s_)
+#endif
+#ifndef WG_KO
+#define WG_KO 0           // diagnostic knock-outs (results wrong): 1 no MFMAs, 2 no fragment reads, 4 no DMA
+#endif
+#define WG_NI (16 / WG_NL)
+#ifdef WG_STAMPS              // diagnostic build (tools/wgrad_stamps.sh): s_memtime sums per segment and wave of every 37th block
+__device__ long long* g_wg_stamps_dev;
+#define WG_STAMP_DECL unsigned long long st_prev__ = 0, st_acc__[4] = {0, 0, 0, 0}
+#define WG_STAMP_START()                                                                               \
+  do {                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev__)::"memory");                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+#define WG_STAMP(seg_)                                                                                 \
+  do {                                                                                                 \
+    unsigned long long t__;                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    st_acc__[seg_] += t__ - st_prev__;                                                                 \
+    st_prev__ = t__;                                                                                   \
+  } while (0)
+#define WG_STAMP_OUT()                                                                                 \
+  do {                                                                                                 \
+    if (g_wg_stamps_dev && blockIdx.x % 37 == 0 && lane == 0) {                                        \
+      unsigned long long rt1__;                                                                        \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1__)::"memory");               \
+      long long* o__ = g_wg_stamps_dev + ((size_t)(blockIdx.x / 37) * (4 + WG_NL) + wave8) * 8;        \
+      for (int i__ = 0; i__ < 4; ++i__) o__[i__] = (long long)st_acc__[i__];                           \
+      o__[4] = (long long)(rt1__ - rt0__);                                                             \
+      o__[5] = n_stages;                                                                               \
+    }                                                                                                  \
+  } while (0)
+#else
+#define WG_STAMP_DECL
+#define WG_STAMP_START()
+#define WG_STAMP(seg_)
+#define WG_STAMP_OUT()
+#endif   // DMA instructions per operand, loader and stage (4 token rows each)
 template <bool PARTIAL>
-__global__ __launch_bounds__(256, 2) void k_wgrad128_bf16(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256 + 64 * WG_NL, 1) void k_wgrad128_bf16(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                           float* __restrict__ dw, int lddw, int L, int N, int K, int tokens_per_block,
                                                           float* __restrict__ part, int tiles_n, int tiles_k, int splits) {
-  __shared__ __attribute__((aligned(16))) char wg[2 * WG_STAGE_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char wg[];      // WG_RING stages of WG_STAGE_BYTES
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = loader ? wave8 - 4 : wave8;   // loader index / compute wave
   const int wn = wave & 1, wk = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4, tq = l15 >> 2, tp = l15 & 3;
   // XCD-aware work mapping: consecutive block ids go round-robin over the 8 XCDs (each with its own L2), so the token range
@@ -722,44 +788,102 @@ __global__ __launch_bounds__(256, 2) void k_wgrad128_bf16(const bf16_t* __restri
   const int t_end = min(L, t_begin + tokens_per_block);
   if (!PARTIAL && t_begin >= t_end) return;
   const uint32_t wg_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&wg[0];
+  const int n_stages = t_begin < t_end ? (t_end - t_begin + 63) / 64 : 0;
 
-  // DMA lane mapping: instruction i of wave w covers tile rows 4*(4w+i) .. +3 (lane>>4 picks the row), LDS chunk = lane&15
-  uint32_t voy[4], vox[4];
-  int cy[4], cx[4];
+  if (loader) {
+    // ================= loader waves: stage s -> ring slot s % WG_RING =================
+    // DMA lane mapping: instruction i of loader w covers tile rows 4*(4w+i) .. +3 (lane>>4 picks the row), LDS chunk = lane&15
+    uint32_t voy[WG_NI], vox[WG_NI];
+    int cy[WG_NI], cx[WG_NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int g = kq | ((i >> 1) << 2);
-    const int ch = l15 ^ (g << 1);
-    cy[i] = (n0 + ch * 8 < N) ? ch * 8 : 0;
-    cx[i] = (k0 + ch * 8 < K) ? ch * 8 : 0;
-    const int r = (wave * 4 + i) * 4 + kq;
-    voy[i] = (uint32_t)(r * lddy + cy[i]) * 2u;
-    vox[i] = (uint32_t)(r * ldx + cx[i]) * 2u;
-  }
+    for (int i = 0; i < WG_NI; ++i) {
+      const int g = kq | ((((wave * WG_NI + i) >> 1) & 1) << 2);
+      const int ch = l15 ^ (g << 1);
+      cy[i] = (n0 + ch * 8 < N) ? ch * 8 : 0;
+      cx[i] = (k0 + ch * 8 < K) ? ch * 8 : 0;
+      const int r = (wave * WG_NI + i) * 4 + kq;
+      voy[i] = (uint32_t)(r * lddy + cy[i]) * 2u;
+      vox[i] = (uint32_t)(r * ldx + cx[i]) * 2u;
+    }
 #define WG_DMA(voff_, base_, dst_)                                                                              \
   do {                                                                                                          \
     unsigned keep__;                                                                                            \
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
                  : "=&s"(keep__) : "v"(voff_), "s"(base_), "s"(dst_) : "memory");                                \
   } while (0)
-#define WG_STAGE(t0_, buf_)                                                                                     \
+    // the loader's eight instructions of stage s_ (first token t_begin + 64 s_); stages past the range are not issued
+#define WG_ISSUE(s_)                                                                                            \
   do {                                                                                                          \
-    const bf16_t* by__ = dy + (size_t)(t0_) * lddy + n0;                                                        \
-    const bf16_t* bx__ = x + (size_t)(t0_) * ldx + k0;                                                          \
-    const int last__ = t_end - 1 - (t0_);                                                                       \
-    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                       \
-      const uint32_t dst__ = wg_lds + (buf_) * WG_STAGE_BYTES + (wave * 4 + i__) * 1024;                        \
-      uint32_t vy__ = voy[i__], vx__ = vox[i__];                                                                \
-      if (last__ < 63) {                                                                                        \
-        const int r__ = min((wave * 4 + i__) * 4 + kq, last__);                                                 \
-        vy__ = (uint32_t)(r__ * lddy + cy[i__]) * 2u;                                                           \
-        vx__ = (uint32_t)(r__ * ldx + cx[i__]) * 2u;                                                            \
+    if ((s_) < n_stages) {                                                                                      \
+      const int t0__ = t_begin + 64 * WG_SRC_STAGE(s_);                                                         \
+      const bf16_t* by__ = dy + (size_t)t0__ * lddy + n0;                                                       \
+      const bf16_t* bx__ = x + (size_t)t0__ * ldx + k0;                                                         \
+      const int last__ = t_end - 1 - t0__;                                                                      \
+      _Pragma("unroll") for (int i__ = 0; i__ < WG_NI; ++i__) {                                                     \
+        const uint32_t dst__ = wg_lds + ((s_) % WG_RING) * WG_STAGE_BYTES + (wave * WG_NI + i__) * 1024;      \
+        uint32_t vy__ = voy[i__], vx__ = vox[i__];                                                              \
+        if (last__ < 63) {                                                                                      \
+          const int r__ = min((wave * WG_NI + i__) * 4 + kq, last__);                                               \
+          vy__ = (uint32_t)(r__ * lddy + cy[i__]) * 2u;                                                         \
+          vx__ = (uint32_t)(r__ * ldx + cx[i__]) * 2u;                                                          \
+        }                                                                                                       \
+        if (!(WG_KO & 4)) {                                                                                     \
+          WG_DMA(vy__, by__, dst__);                                                                            \
+          WG_DMA(vx__, bx__, dst__ + WG_OP_BYTES);                                                              \
+        }                                                                                                       \
       }                                                                                                         \
-      WG_DMA(vy__, by__, dst__);                                                                                \
-      WG_DMA(vx__, bx__, dst__ + WG_OP_BYTES);                                                                  \
     }                                                                                                           \
   } while (0)
+    // rows of stage s_ past the token range (both operands; the loader zeroes the rows it fetched, after its own wait for them)
+#define WG_ZERO_TAIL(s_)                                                                                        \
+  do {                                                                                                          \
+    if ((s_) < n_stages && t_end - (t_begin + 64 * (s_)) < 64) {                                                \
+      _Pragma("unroll") for (int i__ = 0; i__ < WG_NI; ++i__) {                                                     \
+        const int r__ = (wave * WG_NI + i__) * 4 + kq;                                                              \
+        if (t_begin + 64 * (s_) + r__ >= t_end) {                                                               \
+          char* d__ = wg + ((s_) % WG_RING) * WG_STAGE_BYTES + r__ * 256 + l15 * 16;                      \
+          *reinterpret_cast<uint4*>(d__) = make_uint4(0u, 0u, 0u, 0u);                                          \
+          *reinterpret_cast<uint4*>(d__ + WG_OP_BYTES) = make_uint4(0u, 0u, 0u, 0u);                            \
+        }                                                                                                       \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+    WG_ISSUE(0);
+    WG_ISSUE(1);
+    if (WG_RING == 4) WG_ISSUE(2);
+    WG_STAMP_DECL;
+#ifdef WG_STAMPS
+    unsigned long long rt0__;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0__)::"memory");
+#endif
+    if (n_stages > 0) {
+      // stages 0 and 1 complete for this loader (stage 2's eight instructions, if issued, stay in flight)
+      if (WG_RING == 4 && n_stages > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WG_NI) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WG_ZERO_TAIL(0);
+      WG_ZERO_TAIL(1);
+      __syncthreads();                        // barrier P: stages 0, 1 complete
+    }
+    WG_STAMP_START();
+    for (int st = 0; st < n_stages; ++st) {
+      if (st > 0) {
+        // stage st+1 complete (issued two stages ago); stage st+2's instructions - if that stage exists - stay in flight
+        if (WG_RING == 4 && st + 2 < n_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WG_NI) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WG_STAMP(0);
+        WG_ZERO_TAIL(st + 1);
+        __syncthreads();                      // barrier st: stages <= st+1 complete; the compute waves have left stage st-1
+        WG_STAMP(1);
+      }
+      WG_ISSUE(st + WG_RING - 1);             // into the slot of stage st-1
+      WG_STAMP(2);
+    }
+    WG_STAMP_OUT();
+#undef WG_ZERO_TAIL
+#undef WG_ISSUE
+#undef WG_DMA
+    return;
+  }
 
+  // ================= compute waves =================
   // fragment read offsets: token row = 32*st + 8*kq + tq (+4 for the upper half of the 8 tokens), g is the same for all of them
   const int g2 = tq | ((kq & 1) << 2);
   const int rowoff = (kq * 8 + tq) * 256 + (tp & 1) * 8;
@@ -769,6 +893,29 @@ __global__ __launch_bounds__(256, 2) void k_wgrad128_bf16(const bf16_t* __restri
     offa[i] = rowoff + (((wn * 8 + i * 2 + (tp >> 1)) ^ (g2 << 1)) << 4);
     offb[i] = rowoff + (((wk * 8 + i * 2 + (tp >> 1)) ^ (g2 << 1)) << 4) + WG_OP_BYTES;
   }
+  // the 16 transposed reads of one sub-step (st_ = 0 / 1) of the stage at sb_ -> a_[4], b_[4]
+#define WG_FRAGS(sb_, st_, a_, b_)                                                                              \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int j__ = 0; j__ < 4; ++j__) {                                                       \
+      const bf16x4 lo__ = tr16((sb_) + (st_) * 8192 + offb[j__]), hi__ = tr16((sb_) + (st_) * 8192 + 1024 + offb[j__]); \
+      b_[j__] = (bf16x8){lo__[0], lo__[1], lo__[2], lo__[3], hi__[0], hi__[1], hi__[2], hi__[3]};               \
+    }                                                                                                           \
+    _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                       \
+      const bf16x4 lo__ = tr16((sb_) + (st_) * 8192 + offa[i__]), hi__ = tr16((sb_) + (st_) * 8192 + 1024 + offa[i__]); \
+      a_[i__] = (bf16x8){lo__[0], lo__[1], lo__[2], lo__[3], hi__[0], hi__[1], hi__[2], hi__[3]};               \
+    }                                                                                                           \
+  } while (0)
+  // one sub-step's 16 MFMAs with the 16 reads of the next one under the first eight of them (two per gap, the B fragments - which
+  // the next sub-step's first four MFMAs need - first): every read has a full LDS latency of matrix work behind it
+#define WG_GAPS()                                                                                               \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int g__ = 0; g__ < 8; ++g__) {                                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                        \
+    }                                                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  } while (0)
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -776,45 +923,45 @@ __global__ __launch_bounds__(256, 2) void k_wgrad128_bf16(const bf16_t* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (t_begin < t_end) WG_STAGE(t_begin, 0);
-  int buf = 0;
-  for (int t0 = t_begin; t0 < t_end; t0 += 64, buf ^= 1) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of stage `buf` has landed
-    if (t_end - t0 < 64) {                // zero the rows past the token range (both operands)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 4 + kq;
-        if (t0 + r >= t_end) {
-          char* d = wg + buf * WG_STAGE_BYTES + r * 256 + l15 * 16;
-          *reinterpret_cast<uint4*>(d) = make_uint4(0u, 0u, 0u, 0u);
-          *reinterpret_cast<uint4*>(d + WG_OP_BYTES) = make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
-    }
-    __syncthreads();   // stage `buf` complete; every wave has finished reading stage buf^1
-    if (t0 + 64 < t_end) WG_STAGE(t0 + 64, buf ^ 1);
-    const char* sb = wg + buf * WG_STAGE_BYTES;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      bf16x8 a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16x4 lo = tr16(sb + st * 8192 + offa[i]), hi = tr16(sb + st * 8192 + 1024 + offa[i]);
-        a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x4 lo = tr16(sb + st * 8192 + offb[j]), hi = tr16(sb + st * 8192 + 1024 + offb[j]);
-        b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+  bf16x8 a0[4], b0[4], a1[4], b1[4];
+  if (n_stages > 0) {
+    __syncthreads();                          // barrier P
+    WG_FRAGS(wg, 0, a0, b0);
   }
-#undef WG_STAGE
-#undef WG_DMA
+  WG_STAMP_DECL;
+#ifdef WG_STAMPS
+  unsigned long long rt0__;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0__)::"memory");
+#endif
+  WG_STAMP_START();
+  for (int st = 0; st < n_stages; ++st) {
+    const char* sb = wg + (st % WG_RING) * WG_STAGE_BYTES;
+    const char* sn = wg + ((st + 1) % WG_RING) * WG_STAGE_BYTES;
+    if (st > 0) __syncthreads();              // barrier st (sub-step 0's fragments of this stage are already in a0 / b0)
+    WG_STAMP(0);
+    // sub-step 0 | reads of sub-step 1
+    if (!(WG_KO & 2)) WG_FRAGS(sb, 1, a1, b1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (!(WG_KO & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    }
+    WG_GAPS();
+    WG_STAMP(1);
+    // sub-step 1 | reads of the next stage's sub-step 0 (that stage was complete at this stage's barrier)
+    // (behind the last stage this reads a ring slot nobody filled: the values are not used)
+    if (!(WG_KO & 2)) WG_FRAGS(sn, 0, a0, b0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (!(WG_KO & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
+    WG_GAPS();
+    WG_STAMP(2);
+  }
+  WG_STAMP_OUT();
+#undef WG_GAPS
+#undef WG_FRAGS
   if (PARTIAL) {
     const size_t blk = (size_t)tile * splits + split;
     f32x4* dst = reinterpret_cast<f32x4*>(part) + blk * 4096 + wave * 1024 + lane;
@@ -962,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ dy,
 }
 
 static int wgrad_target_blocks() {
-  static const int v = getenv("TTV_WGRAD_BLOCKS") ? atoi(getenv("TTV_WGRAD_BLOCKS")) : 256;
+  static const int v = getenv("TTV_WGRAD_BLOCKS") ? atoi(getenv("TTV_WGRAD_BLOCKS")) : 200;
   return v < 1 ? 1 : v;
 }
 static int wgrad_min_steps() {
@@ -972,8 +1119,9 @@ static int wgrad_min_steps() {
 static void wgrad_plan(int L, int N, int K, int* splits, int* tpb) {
   const int nb = ttv_cdiv(N, 128) * ttv_cdiv(K, 128);
   // token ranges: a multiple of 8 (one per XCD and round), about wgrad_target_blocks() blocks in all - the per-block tile
-  // write-out is the fixed cost, so more blocks than ~1 per CU only add traffic (256 since the GEMMs run beside the dX chain on
-  // their own stream, 384 before; tools/wgrad_plan_sweep.sh)
+  // write-out is the fixed cost, and the kernel runs ONE block per CU (its ring is 128 KB of LDS): the rounding below must stay
+  // under 256 blocks or a second, nearly empty round follows (200: 176 - 192 blocks at the tiny tower's shapes; 256 and two blocks per
+  // CU before round 5, tools/wgrad_plan_sweep.sh)
   int sp = 8 * ((wgrad_target_blocks() + 4 * nb) / (8 * nb));
   // ... and a block should have wgrad_min_steps() 64-token steps to amortise its 64 KB partial tile (written here, read again by the sum)
   const int cap = 8 * (L / (64 * wgrad_min_steps() * 8));
@@ -1002,24 +1150,33 @@ int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int 
       int splits, tpb;
       wgrad_plan(L, N, K, &splits, &tpb);
       const int tn = ttv_cdiv(N, 128), tk = ttv_cdiv(K, 128);
+      static const bool ring_attr = [] {      // 128 KB of dynamic LDS (the 4-slot ring): above the 64 KB a launch gets without asking
+        (void)hipFuncSetAttribute((const void*)k_wgrad128_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_wgrad128_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE_BYTES);
+        return true;
+      }();
+      (void)ring_attr;
+#ifdef WG_STAMPS
+      { extern long long* g_ttv_stamps; long long* p__ = g_ttv_stamps; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wg_stamps_dev), &p__, sizeof(p__), 0, hipMemcpyHostToDevice, s); }
+#endif
       dim3 grid(tn * tk * (splits >= 8 ? 8 * ttv_cdiv(splits, 8) : splits));
       const int64_t need = (int64_t)tn * tk * splits * 65536;
       if (batch && part && ((uintptr_t)part % 16 == 0) && (batch->n == TTV_WGRAD_BATCH || batch->used_bytes + need > part_bytes))
         BW_TRY(ttvk_wgrad_flush(batch, s));        // does not fit behind what is pending: sum that first, start over at the scratch's base
       if (batch && part && ((uintptr_t)part % 16 == 0) && batch->used_bytes + need <= part_bytes) {
         float* mine = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + batch->used_bytes);
-        hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
+        hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256 + 64 * WG_NL), WG_RING * WG_STAGE_BYTES, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
                            tpb, mine, tn, tk, splits);
         WgradBatch::Entry& en = batch->e[batch->n++];
         en.part = mine; en.dw = dw; en.splits = splits; en.lddw = lddw; en.N = N; en.K = K; en.tiles_n = tn; en.tiles = tn * tk;
         batch->used_bytes += need;
       } else if (part && part_bytes >= need && ((uintptr_t)part % 16 == 0)) {
         if (batch) BW_TRY(ttvk_wgrad_flush(batch, s));
-        hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
+        hipLaunchKernelGGL(k_wgrad128_bf16<true>, grid, dim3(256 + 64 * WG_NL), WG_RING * WG_STAGE_BYTES, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
                            tpb, part, tn, tk, splits);
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(tn * tk * 64), dim3(256), 0, s, part, splits, dw, lddw, N, K, tn);
       } else {
-        hipLaunchKernelGGL(k_wgrad128_bf16<false>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
+        hipLaunchKernelGGL(k_wgrad128_bf16<false>, grid, dim3(256 + 64 * WG_NL), WG_RING * WG_STAGE_BYTES, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, lddw, L, N, K,
                            tpb, nullptr, tn, tk, splits);
       }
     } else {

@@ -11,7 +11,7 @@ from titok_video_amd import _lib  # noqa: E402
 DEV = torch.device("cuda:0")
 lib = _lib.lib()
 S = _lib.stream_ptr(DEV)
-L = 36864
+L = int(os.environ.get("L", "36864"))
 for name, N, K in (("w3", 256, 704), ("w12", 1408, 256), ("out_proj", 256, 256), ("to_qkv", 768, 256), ("proj_in", 256, 768)):
     dy = torch.randn(L, N, device=DEV).bfloat16()
     x = torch.randn(L, K, device=DEV).bfloat16()
