@@ -437,6 +437,20 @@ int ttv_decoder_backward(const ttv_tower_dims* dims, const ttv_tower_weights* w,
 /* Straight-through FSQ backward (fsq.py:48-51,78-90): dz = dcodes * half_l/half_width * (1 - tanh^2(z + shift)). */
 int ttv_fsq_backward(const ttv_fsq_params* p, const float* z, const void* dcodes, int dcodes_dtype, float* dz, int rows, void* stream);
 
+/* Optimizer step of the training loop (reference train.py:76-77 clip_gradients + :183-190 optim.AdamW; the arithmetic of
+ * torch.nn.utils.clip_grad_norm_ followed by torch.optim.AdamW, fp32 whatever the tensors' dtype) over a list of tensors, in two launches.
+ * table  : device array of n entries {void* param; const void* grad; void* exp_avg; void* exp_avg_sq; int64 numel} (40 bytes each; param,
+ *          exp_avg and exp_avg_sq of one dtype - TTV_F32 or TTV_BF16 - which is also the gradient's);
+ * chunks : device int32 [n_chunks][2] = (entry index, first element): one block per chunk of up to 8192 elements.
+ * ttv_opt_grad_sumsq writes partials[c] = sum of grad^2 over chunk c.  ttv_opt_adamw_step sums partials[0 .. n_partials) in a fixed order
+ * (all chunks of ALL tensor lists of the step: the global gradient norm, written to out_norm when not NULL), scales the gradients by
+ * min(1, max_norm / (norm + 1e-6)) in registers (max_norm <= 0 or n_partials == 0: no clipping; p.grad is NOT rewritten) and applies
+ * AdamW with the given bias corrections 1 - beta1^t and sqrt(1 - beta2^t). */
+int ttv_opt_grad_sumsq(const void* table, const int32_t* chunks, int n_chunks, int dtype, float* partials, void* stream);
+int ttv_opt_adamw_step(const void* table, const int32_t* chunks, int n_chunks, int dtype, const float* partials, int n_partials, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2_sqrt,
+                       float max_norm, float* out_norm, void* stream);
+
 /* Single backward ops, exported for parity tests. */
 /* dW[N,K] (fp32, accumulated) += dY[L,N]^T X[L,K]  (weight gradient of y = x w^T; what autograd computes for the
  * nn.Linear weights of base/blocks.py:70-84,147-148).  The token range is split over blocks; with a workspace of

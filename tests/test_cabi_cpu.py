@@ -86,3 +86,18 @@ def test_workspace_size_is_deterministic(handle):
                  [L * 256 * 2, L * 256 * 2, L * 768 * 2, L * 256 * 2, L * 256 * 4, L * 704 * 2, P * 768 * 2, P * 256 * 2, L * 4,
                   4096 * 256 * 2, 4096 * 256 * 2])   # + rstd; + the compact latent rows of x and of the attention output (encoder, last layer)
     assert n == expect
+
+
+def test_hip_adamw_has_no_cpu_path():
+    """optim.HipAdamW steps on the GPU only: parameters on the host raise, and make_optimizer() gives host parameters torch's AdamW."""
+    import pytest
+    import torch
+    from titok_video_amd.optim import HipAdamW
+    from titok_video_amd.train import make_optimizer
+    p = torch.nn.Parameter(torch.ones(8))
+    p.grad = torch.ones(8)
+    opt = HipAdamW([p], lr=1e-3)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        opt.step()
+    lin = torch.nn.Linear(4, 4)
+    assert type(make_optimizer(lin)) is torch.optim.AdamW

@@ -143,6 +143,8 @@ SYMBOLS = {
     "ttv_fsq_backward": (C.c_int, [C.POINTER(FsqParams), vp, vp, C.c_int, vp, C.c_int, vp]),
     "ttv_rmsnorm_backward_chain": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_float, vp, C.c_int,
                                               C.c_int, C.c_int, C.c_float, C.c_int, vp]),
+    "ttv_opt_grad_sumsq": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "ttv_opt_adamw_step": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int] + [C.c_float] * 8 + [vp, vp]),
     "ttv_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "ttv_linear_wgrad": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
     "ttv_rmsnorm_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, f32, C.c_int, vp]),

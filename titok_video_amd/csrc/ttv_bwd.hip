@@ -504,6 +504,35 @@ __global__ __launch_bounds__(256) void k_geglu_bwd(const T* __restrict__ u, int 
     Vec4<T>::store(du + r * lddu + I + c, o2);
   }
 }
+// bf16 form: 16-byte accesses (8 features per thread) and Phi(g) = sigmoid(p(g)) of the forward's geglu_fast() (ttv_common.h: |g Phi - gelu| <= 2.6e-5,
+// a tenth of a bf16 half-ulp) instead of erff() - with erff() and expf() per element the kernel was bound by its ~60 VALU instructions per
+// element, not by its 260 MB (round 5: 44.7 -> see profiles/r05_train_geglu_bwd.txt).  gelu'(g) = Phi(g) + g phi(g), phi by one v_exp_f32.
+__global__ __launch_bounds__(256) void k_geglu_bwd_bf16(const bf16_t* __restrict__ u, int ldu, const bf16_t* __restrict__ dh, int lddh,
+                                                        bf16_t* __restrict__ du, int lddu, int rows, int I) {
+  const int i8 = I / 8;
+  const long total = (long)rows * i8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / i8;
+    const int c = (int)(i - r * i8) * 8;
+    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(u + r * ldu + c), gv = *reinterpret_cast<const bf16x8*>(u + r * ldu + I + c);
+    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dh + r * lddh + c);
+    bf16x8 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float g = (float)gv[e], d = (float)dv[e], x = (float)xv[e];
+      const float gc = __builtin_amdgcn_fmed3f(g, -8.0f, 8.0f);
+      const float g2 = gc * gc;
+      float q = fmaf(g2, 1.014262858e-03f, -1.067757308e-01f);
+      q = fmaf(q, g2, -2.301121361e+00f);
+      const float cdf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q * gc));
+      const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * (g * g));
+      o1[e] = (bf16_t)(d * (g * cdf));
+      o2[e] = (bf16_t)(d * x * fmaf(g, pdf, cdf));
+    }
+    *reinterpret_cast<bf16x8*>(du + r * lddu + c) = o1;
+    *reinterpret_cast<bf16x8*>(du + r * lddu + I + c) = o2;
+  }
+}
 // b = alpha * a (fp32 -> fp32, may alias), c = (T) a
 template <typename T>
 __global__ __launch_bounds__(256) void k_scale_cast(const float* __restrict__ a, float alpha, float* __restrict__ b, T* __restrict__ c, long n4) {
@@ -557,7 +586,10 @@ int ttvk_geglu_fwd(const void* u, int ldu, void* h, int ldh, int rows, int I, in
 int ttvk_geglu_bwd(const void* u, int ldu, const void* dh, int lddh, void* du, int lddu, int rows, int I, int dt, hipStream_t s) {
   if (rows == 0) return TTV_OK;
   const int nb = ew_blocks((long)rows * I / 4);
-  if (dt == TTV_BF16) hipLaunchKernelGGL((k_geglu_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)u, ldu, (const bf16_t*)dh, lddh, (bf16_t*)du, lddu, rows, I);
+  static const bool exact = getenv("TTV_GEGLU_BWD_ERF") && getenv("TTV_GEGLU_BWD_ERF")[0] == '1';      // A/B: the erff() form
+  const bool v8 = !exact && I % 8 == 0 && ldu % 8 == 0 && lddh % 8 == 0 && lddu % 8 == 0 && ((uintptr_t)u % 16 == 0) && ((uintptr_t)dh % 16 == 0) && ((uintptr_t)du % 16 == 0);
+  if (dt == TTV_BF16 && v8) hipLaunchKernelGGL(k_geglu_bwd_bf16, dim3(ew_blocks((long)rows * I / 8)), dim3(256), 0, s, (const bf16_t*)u, ldu, (const bf16_t*)dh, lddh, (bf16_t*)du, lddu, rows, I);
+  else if (dt == TTV_BF16) hipLaunchKernelGGL((k_geglu_bwd<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)u, ldu, (const bf16_t*)dh, lddh, (bf16_t*)du, lddu, rows, I);
   else hipLaunchKernelGGL((k_geglu_bwd<float>), dim3(nb), dim3(256), 0, s, (const float*)u, ldu, (const float*)dh, lddh, (float*)du, lddu, rows, I);
   TTV_CHECK_LAUNCH("geglu_bwd");
   return TTV_OK;

@@ -9,11 +9,13 @@ mirror; LPIPS is outside this path's scope (network-fetched weights, SURVEY.md s
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import dp
+from .optim import HipAdamW, use_hip_adamw
 
 
 class _L1LossFn(torch.autograd.Function):
@@ -101,8 +103,25 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, beta1: float = 0.5,
     """AdamW with the reference's hyper-parameters (configs/tiny.yaml:39-46, train.py:170-190).  capturable=True keeps the step
     counter on the device so that the step can be recorded into a HIP graph (GraphedTrainingStep)."""
     params = [p for p in model.parameters() if p.requires_grad]
+    # parameters on the GPU: clip + AdamW as two HIP launches (optim.HipAdamW; TTV_HIP_ADAMW=0 keeps torch's multi-tensor kernels, and
+    # so does capturable=True - the HIP step takes its step count from the host)
+    if use_hip_adamw(params) and not capturable and os.environ.get("TTV_HIP_ADAMW", "1") != "0":
+        return HipAdamW(params, lr=lr, betas=(beta1, beta2), weight_decay=weight_decay)
     fused = bool(params) and all(p.is_cuda for p in params)      # one multi-tensor kernel instead of a launch per parameter
     return torch.optim.AdamW(params, lr=lr, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused, capturable=capturable and fused)
+
+
+def clip_and_step(optimizer, params, max_grad_norm):
+    """clip_grad_norm_(params, max_grad_norm) (skipped when max_grad_norm is falsy) + optimizer.step(); returns the gradient norm or None.
+    HipAdamW does both in its own two launches (the norm is taken over the optimizer's parameters that have a gradient - the same set)."""
+    if isinstance(optimizer, HipAdamW):
+        if max_grad_norm:
+            return optimizer.clip_and_step(max_grad_norm)
+        optimizer.step()
+        return None
+    gnorm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm) if max_grad_norm else None
+    optimizer.step()
+    return gnorm
 
 
 def _reducer_for(model, group, overlap: bool):
@@ -153,8 +172,7 @@ def training_step(model, clips: List[torch.Tensor], token_counts, optimizer, max
         red.reduce_rest(params, len(clips))            # trainable parameters outside the towers (none in the reference's TiTok)
     else:
         dp.allreduce_mean_by_count([p.grad for p in params], len(clips), group=group)
-    gnorm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
-    optimizer.step()
+    gnorm = clip_and_step(optimizer, params, max_grad_norm)
     return loss.detach(), gnorm, out["indices"]
 
 
@@ -258,9 +276,7 @@ def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_count
         red.reduce_rest(g_params, len(clips))
     else:
         dp.allreduce_mean_by_count([p.grad for p in g_params], len(clips), group=group)
-    if max_grad_norm:
-        torch.nn.utils.clip_grad_norm_(g_params, max_grad_norm)
-    opt_g.step()
+    clip_and_step(opt_g, g_params, max_grad_norm)
     if opt_d is not None and getattr(loss_module, "disc_weight", 0.0) > 0.0:
         opt_d.zero_grad(set_to_none=True)
         if red is not None:
@@ -280,7 +296,5 @@ def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_count
             red.reduce_rest(d_params, len(clips))
         else:
             dp.allreduce_mean_by_count([p.grad for p in d_params], len(clips), group=group)
-        if max_grad_norm:
-            torch.nn.utils.clip_grad_norm_(d_params, max_grad_norm)
-        opt_d.step()
+        clip_and_step(opt_d, d_params, max_grad_norm)
     return loss_dict, out["indices"]
