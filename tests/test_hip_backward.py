@@ -48,7 +48,7 @@ def config():
 # ---------------------------------------------------------------------------------------------- single kernels
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(1000, 256, 768), (333, 768, 256), (2500, 1408, 256), (130, 256, 704), (36864, 768, 256), (64, 256, 256),
-                                   (70, 8, 264), (4097, 136, 120)])
+                                   (70, 8, 264), (4097, 136, 120), (1500, 256, 256), (2000, 264, 136), (1090, 128, 128)])   # 3 / 4 / 3 (last one ragged) stages per block: the ring's edges
 @pytest.mark.parametrize("workspace", [False, True])
 def test_wgrad(dt, shape, workspace):
     Lr, N, K = shape
