@@ -160,10 +160,10 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return v;
 }
 
-template <typename T, int ITERS>
+template <typename T, typename YT, int ITERS>
 __global__ __launch_bounds__(256) void k_rmsnorm_bwd_chain(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                            const float* __restrict__ gain1, float* __restrict__ dgain1, float* dx, int lddx,
-                                                           const float* __restrict__ y, int ldy, const float* __restrict__ gain2,
+                                                           const YT* __restrict__ y, int ldy, const float* __restrict__ gain2,
                                                            float* __restrict__ dgain2, float out_scale, T* __restrict__ cast_out, int ldc,
                                                            int rows, int d, float eps, int rows_per_wave) {
   __shared__ float red[4][ITERS * 256];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_bwd_chain(const T* __restrict__
           xv[q][it] = Vec4<T>::load(x + (size_t)r * ldx + c);
           gv[q][it] = Vec4<T>::load(dy + (size_t)r * lddy + c);
           hv[q][it] = *reinterpret_cast<const f32x4*>(dx + (size_t)r * lddx + c);
-          if (second) yv[q][it] = *reinterpret_cast<const f32x4*>(y + (size_t)r * ldy + c);
+          if (second) yv[q][it] = Vec4<YT>::load(y + (size_t)r * ldy + c);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -298,29 +298,33 @@ __global__ __launch_bounds__(256) void k_rmsnorm_bwd_chain(const T* __restrict__
   }
 }
 
-template <typename T, int ITERS>
+template <typename T, typename YT, int ITERS>
 static void launch_rms_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
-                             const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                             const void* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
                              int d, float eps, hipStream_t s) {
   int rpw = ttv_cdiv(rows, 4 * 512);
   if (rpw < 1) rpw = 1;
-  hipLaunchKernelGGL((k_rmsnorm_bwd_chain<T, ITERS>), dim3(ttv_cdiv(rows, 4 * rpw)), dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy,
-                     gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, (T*)cast_out, ldc, rows, d, eps, rpw);
+  hipLaunchKernelGGL((k_rmsnorm_bwd_chain<T, YT, ITERS>), dim3(ttv_cdiv(rows, 4 * rpw)), dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy,
+                     gain1, dgain1, dx, lddx, (const YT*)y, ldy, gain2, dgain2, out_scale, (T*)cast_out, ldc, rows, d, eps, rpw);
 }
 
+// y_dt: dtype of the second norm's input y (TTV_F32, or TTV_BF16 with dt == TTV_BF16: the bf16 towers' tape keeps the KEEL sums in bf16)
 int ttvk_rmsnorm_bwd_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
-                           const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                           const void* y, int y_dt, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
                            int d, float eps, int dt, hipStream_t s) {
   if (rows == 0) return TTV_OK;
   TTV_CHECK_ARG(d % 4 == 0 && d <= 1024, "rmsnorm_bwd_chain: width");
   TTV_CHECK_ARG(dt == TTV_BF16 || dt == TTV_F32, "rmsnorm_bwd_chain: dtype");
   TTV_CHECK_ARG(!y || gain2, "rmsnorm_bwd_chain: second norm needs its gain");
+  TTV_CHECK_ARG(!y || y_dt == TTV_F32 || (y_dt == TTV_BF16 && dt == TTV_BF16), "rmsnorm_bwd_chain: y is fp32, or bf16 beside bf16 rows");
   const int iters = ttv_cdiv(d, 256);
-#define RC(T, I) launch_rms_chain<T, I>(x, ldx, dy, lddy, gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, cast_out, ldc, rows, d, eps, s)
-  if (dt == TTV_BF16) {
-    if (iters == 1) RC(bf16_t, 1); else if (iters == 2) RC(bf16_t, 2); else RC(bf16_t, 4);
+#define RC(T, YT, I) launch_rms_chain<T, YT, I>(x, ldx, dy, lddy, gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, cast_out, ldc, rows, d, eps, s)
+  if (dt == TTV_BF16 && y && y_dt == TTV_BF16) {
+    if (iters == 1) RC(bf16_t, bf16_t, 1); else if (iters == 2) RC(bf16_t, bf16_t, 2); else RC(bf16_t, bf16_t, 4);
+  } else if (dt == TTV_BF16) {
+    if (iters == 1) RC(bf16_t, float, 1); else if (iters == 2) RC(bf16_t, float, 2); else RC(bf16_t, float, 4);
   } else {
-    if (iters == 1) RC(float, 1); else if (iters == 2) RC(float, 2); else RC(float, 4);
+    if (iters == 1) RC(float, float, 1); else if (iters == 2) RC(float, float, 2); else RC(float, float, 4);
   }
 #undef RC
   TTV_CHECK_LAUNCH("rmsnorm_bwd_chain");

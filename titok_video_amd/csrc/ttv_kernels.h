@@ -142,7 +142,7 @@ int ttvk_sq_err(void* const* recon, void* const* target, const int* sizes, int n
 // dx (fp32, in/out) = out_scale * B(A), cast_out = (T) B(A) with A = dx + rmsnorm_bwd(x, gain1, dy), B = rmsnorm_bwd(y, gain2, .) or
 // identity when y == NULL; gain gradients accumulated with atomics (dgain1 / dgain2 may be NULL); cast_out may be NULL
 int ttvk_rmsnorm_bwd_chain(const void* x, int ldx, const void* dy, int lddy, const float* gain1, float* dgain1, float* dx, int lddx,
-                           const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
+                           const void* y, int y_dt, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
                            int d, float eps, int dt, hipStream_t s);
 int ttvk_rmsnorm_bwd(const void* x, int x_dt, int ldx, const int* xr, const void* dy, int dy_dt, int lddy, const int* dyr,
                      const float* gain, void* dx, int dx_dt, int lddx, const int* dxr, int acc, float* dgain, int rows, int d, float eps,

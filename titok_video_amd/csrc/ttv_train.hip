@@ -24,12 +24,25 @@ struct Tape {
   // per tower
   char *patches, *pe, *hpre, *pn;     // encoder: gathered patches, proj_in output (pre-norm); decoder: pre-norm latent rows, ln_post out
   char* X[65];                        // residual stream at every layer boundary (X[0] = tower input rows, X[layers] = output)
-  struct L { char *xn1, *qkvg, *a, *ag, *x1, *xn2, *u, *h; float *lse, *y1, *y2; } l[64];
+  struct L { char *xn1, *qkvg, *a, *ag, *x1, *xn2, *u, *h, *y1, *y2; float* lse; } l[64];   // y1 / y2: the KEEL sums, dtype tape_y_dtype()
   char *agc, *xc;                     // encoder, last layer: its latent rows of ag and of X[layers - 1], compact (see latent_tail)
 };
 
+// The KEEL sums y = alpha * x + f(x) the post-norms read (forward) and differentiate (backward) are kept in the tower's dtype: a bf16
+// tower rounds them to bf16 as the reference's autocast does (transformer.py:141: bf16 * alpha + bf16) and as the inference path does -
+// half the bytes on the GEMM that writes them, the norm that reads them and the backward chain (round 5; fp32 before).  The opt-in
+// fused-norm tape forward (TTV_TRAIN_FUSED_NORMS=1) writes fp32 sums from its GEMM kernel and keeps fp32.
+static bool tape_fuse_norms() {
+  static const bool v = getenv("TTV_TRAIN_FUSED_NORMS") && getenv("TTV_TRAIN_FUSED_NORMS")[0] == '1';
+  return v;
+}
+static int tape_y_dtype(int dt) {
+  static const bool f32 = getenv("TTV_TAPE_Y_F32") && getenv("TTV_TAPE_Y_F32")[0] == '1';      // A/B: fp32 sums as before round 5
+  return (dt == TTV_F32 || tape_fuse_norms() || f32) ? TTV_F32 : TTV_BF16;
+}
 static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) {
   Tape t;
+  const int64_t ye = esz(tape_y_dtype(d->dtype));
   const int64_t e = esz(d->dtype), L = b->total_rows, P = b->sum_patches, K = b->sum_tokens, dm = d->width;
   const int64_t g = (int64_t)d->kv_heads * d->head_dim, nq = 2 * dm + 2 * g;
   const int64_t pd = (int64_t)d->pix_channels * d->patch_t * d->patch_h * d->patch_w;
@@ -45,8 +58,8 @@ static Tape carve_tape(const ttv_tower_dims* d, const ttv_batch* b, char* base) 
     Tape::L& l = t.l[i];
     l.xn1 = take(L * dm * e); l.qkvg = take(L * nq * e); l.lse = (float*)take(L * d->q_heads * 4);
     l.a = take(L * dm * e); l.ag = take(L * dm * e);
-    l.y1 = (float*)take(i > 0 ? L * dm * 4 : 0); l.x1 = take(L * dm * e); l.xn2 = take(L * dm * e);
-    l.u = take(L * 2 * d->inner * e); l.h = take(L * d->inner * e); l.y2 = (float*)take(i > 0 ? L * dm * 4 : 0);
+    l.y1 = take(i > 0 ? L * dm * ye : 0); l.x1 = take(L * dm * e); l.xn2 = take(L * dm * e);
+    l.u = take(L * 2 * d->inner * e); l.h = take(L * d->inner * e); l.y2 = take(i > 0 ? L * dm * ye : 0);
   }
   t.total = off;
   return t;
@@ -131,7 +144,8 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
   // instead of 9, same tape.  Measured neutral (same box, tools/bench_train.py: 8.234 vs 8.236 ms at 32 clips, 3.47 vs 3.44 ms at 5): the
   // row-owning GEMM kernels lose against the tiled GEMM + 160-token tiles what the four row kernels cost, and the step is GPU-bound, not
   // launch-bound - so the proven sequence stays the default.
-  static const bool fuse_norms = getenv("TTV_TRAIN_FUSED_NORMS") && getenv("TTV_TRAIN_FUSED_NORMS")[0] == '1';
+  const bool fuse_norms = tape_fuse_norms();
+  const int ydt = tape_y_dtype(dt);
   bool xn1_ready = false;          // this layer's xn1 was written by the layer below
   for (int i = 0; i < d->layers; ++i) {
     const ttv_layer_weights& lw = w->layers[i];
@@ -175,12 +189,12 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
       TTV_TRY(ttvk_gemm(EPI_RESID_T, o, s));
     } else if (fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, dm)) {
       o.alpha = d->alpha; o.y = l.x1; o.ldy = dm; o.norm_gain = lw.attn_post_ln; o.eps = d->eps;
-      o.sum_f32 = l.y1; o.ld_sum = dm; o.y2 = l.xn2; o.ldy2 = dm; o.norm_gain2 = lw.ffd_norm;
+      o.sum_f32 = (float*)l.y1; o.ld_sum = dm; o.y2 = l.xn2; o.ldy2 = dm; o.norm_gain2 = lw.ffd_norm;
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, o, s));
     } else {
       o.alpha = d->alpha; o.y = l.y1; o.ldy = dm;
-      TTV_TRY(ttvk_gemm(EPI_RESID_F32, o, s));
-      TTV_TRY(ttvk_rmsnorm(l.y1, TTV_F32, dm, nullptr, l.x1, dt, dm, nullptr, lw.attn_post_ln, Lc, dm, d->eps, s));
+      TTV_TRY(ttvk_gemm(ydt == TTV_F32 ? EPI_RESID_F32 : EPI_RESID_T, o, s));
+      TTV_TRY(ttvk_rmsnorm(l.y1, ydt, dm, nullptr, l.x1, dt, dm, nullptr, lw.attn_post_ln, Lc, dm, d->eps, s));
     }
     if (!(i > 0 && fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, dm)))
       TTV_TRY(ttvk_rmsnorm(l.x1, dt, dm, nullptr, l.xn2, dt, dm, nullptr, lw.ffd_norm, Lc, dm, d->eps, s));
@@ -202,7 +216,7 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
       TTV_TRY(ttvk_gemm(EPI_RESID_T, f3, s));
     } else if (fuse_norms && ttvk_gemm_supports_resid_norm(dt, dm, I)) {
       f3.alpha = d->alpha; f3.y = x_out; f3.ldy = dm; f3.norm_gain = lw.ffd_post_ln; f3.eps = d->eps;
-      f3.sum_f32 = l.y2; f3.ld_sum = dm;
+      f3.sum_f32 = (float*)l.y2; f3.ld_sum = dm;
       if (i + 1 < d->layers) {          // the next layer's pre-norm rides along
         f3.y2 = t.l[i + 1].xn1; f3.ldy2 = dm; f3.norm_gain2 = w->layers[i + 1].pre_ln;
         xn1_ready = true;
@@ -210,8 +224,8 @@ static int layers_forward_train(const ttv_tower_dims* d, const ttv_tower_weights
       TTV_TRY(ttvk_gemm(EPI_RESID_NORM, f3, s));
     } else {
       f3.alpha = d->alpha; f3.y = l.y2; f3.ldy = dm;
-      TTV_TRY(ttvk_gemm(EPI_RESID_F32, f3, s));
-      TTV_TRY(ttvk_rmsnorm(l.y2, TTV_F32, dm, nullptr, x_out, dt, dm, nullptr, lw.ffd_post_ln, Lc, dm, d->eps, s));
+      TTV_TRY(ttvk_gemm(ydt == TTV_F32 ? EPI_RESID_F32 : EPI_RESID_T, f3, s));
+      TTV_TRY(ttvk_rmsnorm(l.y2, ydt, dm, nullptr, x_out, dt, dm, nullptr, lw.ffd_post_ln, Lc, dm, d->eps, s));
     }
     if (lat)     // the latent rows of the tower's output where the tail (and the backward) read them; its patch rows are never read
       TTV_TRY(ttvk_copy_rows(t.xc, (int64_t)dm * esz(dt), nullptr, t.X[i + 1], (int64_t)dm * esz(dt), b->latent_rows, Lc, dm * esz(dt), s));
@@ -276,7 +290,7 @@ static int side_join(WgradSide* sd, hipStream_t s) {
 static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, const ttv_tower_weights_t* wt, const ttv_batch* b, Tape& t,
                            const ttv_tower_grads* gr, BwdWs& ws, hipStream_t s) {
   const int L = b->total_rows, dm = d->width, g = d->kv_heads * d->head_dim, dt = d->dtype, nq = 2 * dm + 2 * g, I = d->inner;
-  const long nLd = (long)L * dm;
+  const int ydt = tape_y_dtype(dt);
   float* dx = ws.dxa;     // gradient of the layer output
   float* tmp = ws.dxb;
   WgradBatch wgb;
@@ -308,7 +322,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     float* dx1;
     if (i == d->layers - 1) {
       if (i > 0) {
-        TTV_TRY(ttvk_rmsnorm_bwd(l.y2, TTV_F32, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, Lc, dm, d->eps, s));
+        TTV_TRY(ttvk_rmsnorm_bwd(l.y2, ydt, dm, nullptr, dx, TTV_F32, dm, nullptr, lw.ffd_post_ln, tmp, TTV_F32, dm, nullptr, 0, lg.ffd_post_ln, Lc, dm, d->eps, s));
         // tmp = dy2 ; df (T) = dy2 ; dx1 = alpha * dy2 (into dx)
         TTV_TRY(ttvk_scale_cast(tmp, d->alpha, dx, df, dt, nLc, s));
       } else {
@@ -332,7 +346,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
     // dx1 += rmsnorm_bwd(x1, ffd_norm, dxn2), then straight through the attention sub-layer's post-norm:
     // ---------------- attention sub-layer: x1 = post_ln(alpha*x + out_proj ag) ----------------
     // i > 0: dy1 = rmsnorm_bwd(y1, attn_post_ln, dx1) ; do = (T) dy1 ; dx = alpha * dy1      i == 0: do = (T) dx1 ; dx = dx1
-    TTV_TRY(ttvk_rmsnorm_bwd_chain(l.x1, dm, ws.g_d2, dm, lw.ffd_norm, lg.ffd_norm, dx1, dm, i > 0 ? l.y1 : nullptr, dm,
+    TTV_TRY(ttvk_rmsnorm_bwd_chain(l.x1, dm, ws.g_d2, dm, lw.ffd_norm, lg.ffd_norm, dx1, dm, i > 0 ? l.y1 : nullptr, ydt, dm,
                                    i > 0 ? lw.attn_post_ln : nullptr, i > 0 ? lg.attn_post_ln : nullptr, i > 0 ? d->alpha : 1.f, ws.g_do, dm, Lc,
                                    dm, d->eps, dt, s));
     TTV_TRY(side_fork(sd, 2, s));          // do is complete
@@ -373,7 +387,7 @@ static int layers_backward(const ttv_tower_dims* d, const ttv_tower_weights* w, 
       TTV_TRY(ttvk_rmsnorm_bwd(t.X[i], dt, dm, nullptr, ws.g_d2, dt, dm, nullptr, lw.pre_ln, dx, TTV_F32, dm, nullptr, 1, lg.pre_ln, L, dm, d->eps, s));
     } else {
       const bool post = i - 1 > 0;
-      TTV_TRY(ttvk_rmsnorm_bwd_chain(t.X[i], dm, ws.g_d2, dm, lw.pre_ln, lg.pre_ln, dx, dm, post ? t.l[i - 1].y2 : nullptr, dm,
+      TTV_TRY(ttvk_rmsnorm_bwd_chain(t.X[i], dm, ws.g_d2, dm, lw.pre_ln, lg.pre_ln, dx, dm, post ? t.l[i - 1].y2 : nullptr, ydt, dm,
                                      post ? w->layers[i - 1].ffd_post_ln : nullptr, post ? gr->layers[i - 1].ffd_post_ln : nullptr,
                                      post ? d->alpha : 1.f, g_df[cur ^ 1], dm, L, dm, d->eps, dt, s));   // df of the layer below (da is consumed)
     }
@@ -672,7 +686,7 @@ int ttv_rmsnorm_backward_chain(const void* x, int ldx, const void* dy, int lddy,
                                const float* y, int ldy, const float* gain2, float* dgain2, float out_scale, void* cast_out, int ldc, int rows,
                                int width, float eps, int dtype, void* stream) {
   TTV_CHECK_ARG(rows == 0 || (x && dy && gain1 && dx), "rmsnorm_backward_chain: null buffer");
-  return ttvk_rmsnorm_bwd_chain(x, ldx, dy, lddy, gain1, dgain1, dx, lddx, y, ldy, gain2, dgain2, out_scale, cast_out, ldc, rows, width, eps,
+  return ttvk_rmsnorm_bwd_chain(x, ldx, dy, lddy, gain1, dgain1, dx, lddx, y, TTV_F32, ldy, gain2, dgain2, out_scale, cast_out, ldc, rows, width, eps,
                                 dtype, (hipStream_t)stream);
 }
 
