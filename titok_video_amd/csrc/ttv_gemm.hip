@@ -173,17 +173,39 @@ __device__ __forceinline__ void epilogue_tile(const GemmDev& p, const int (&tok)
       // training tape: the pre-activations u = [x | gate] (ld = ldr) are kept as well; h is then formed from the STORED (rounded)
       // values, exactly what a separate GEGLU pass over u would see
       T* u = (T*)const_cast<void*>(p.resid);
+      if (sizeof(T) == 2 && (NI % 2 == 0) && p.N % 8 == 0 && p.ldr % 8 == 0) {
+        // 16-byte stores as at the end of this function: lanes kq / kq ^ 1 exchange one 4-feature group of each half (round 5; 8-byte before)
+        const bool odd = kq & 1;
+#pragma unroll
+        for (int ip = 0; ip < NI / 2; ++ip) {
+          const int i0 = 2 * ip, i1 = 2 * ip + 1;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const uint4 ox = xchg16_pair(pack_bf16x4(acc[i0][j]), pack_bf16x4(acc[i1][j]));
+            const uint4 og = xchg16_pair(pack_bf16x4(acc2[i0][j]), pack_bf16x4(acc2[i1][j]));
+            const int start = odd ? feat[i1] - 4 : feat[i0];
+            if (tv[j] && start + 8 <= p.N) {
+              *reinterpret_cast<uint4*>(u + (size_t)tok[j] * p.ldr + start) = ox;
+              *reinterpret_cast<uint4*>(u + (size_t)tok[j] * p.ldr + p.N + start) = og;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            if (tv[j] && fv[i]) {
+              Vec4<T>::store(u + (size_t)tok[j] * p.ldr + feat[i], acc[i][j]);
+              Vec4<T>::store(u + (size_t)tok[j] * p.ldr + p.N + feat[i], acc2[i][j]);
+            }
+      }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (tv[j] && fv[i]) {
-            Vec4<T>::store(u + (size_t)tok[j] * p.ldr + feat[i], acc[i][j]);
-            Vec4<T>::store(u + (size_t)tok[j] * p.ldr + p.N + feat[i], acc2[i][j]);
-          }
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { acc[i][j][e] = round_to<T>(acc[i][j][e]); acc2[i][j][e] = round_to<T>(acc2[i][j][e]); }
-        }
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
