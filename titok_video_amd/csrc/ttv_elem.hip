@@ -159,12 +159,57 @@ static int launch_rmsnorm(const void* in, int ld_in, const int* src_rows, void* 
   return TTV_OK;
 }
 
+// Width 256, bf16 in and out, no row maps and no side outputs - the 31 norms of a training step's tape forward (and every other plain
+// call at that width): half a wave per row with 16-byte accesses, eight rows of a wave in flight at once, 1 152 blocks for 36 864 rows.
+// The one-row-per-wave kernel above issues ONE 8-byte load per lane and waits for it: 11 us for 38 MB (3.5 TB/s) - latency, not bandwidth.
+__global__ __launch_bounds__(256) void k_rmsnorm256_bf16(const bf16_t* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
+                                                         const float* __restrict__ gain, int rows, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, c = (lane & 31) * 8;
+  const int r0 = (blockIdx.x * 4 + wave) * 8;
+  if (r0 >= rows) return;
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(gain + c), g1 = *reinterpret_cast<const f32x4*>(gain + c + 4);
+  bf16x8 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + 2 * k + half;
+    v[k] = *reinterpret_cast<const bf16x8*>(in + (size_t)(r < rows ? r : rows - 1) * ld_in + c);
+  }
+  float ss[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ss[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)v[k][e]; ss[k] = fmaf(f, f, ss[k]); }
+  }
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ss[k] += __shfl_xor(ss[k], o, 64);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + 2 * k + half;
+    const float rstd = 1.0f / sqrtf(ss[k] * (1.0f / 256.0f) + eps);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)((float)v[k][e] * rstd * g0[e]); o[e + 4] = (bf16_t)((float)v[k][e + 4] * rstd * g1[e]); }
+    if (r < rows) *reinterpret_cast<bf16x8*>(out + (size_t)r * ld_out + c) = o;
+  }
+}
+
 int ttvk_rmsnorm(const void* in, int in_dtype, int ld_in, const int* src_rows, void* out, int out_dtype, int ld_out,
                  const int* dst_rows, const float* gain, int rows, int d, float eps, hipStream_t s, float* next_rstd, void* mx_q, void* mx_s,
                  int split_image) {
   TTV_CHECK_ARG(d % 4 == 0 && d <= 64 * 4 * MAX_ITERS, "rmsnorm: width %d must be a multiple of 4 and <= 1024", d);
   TTV_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "rmsnorm: leading dims must be multiples of 4");
   TTV_CHECK_ARG(!mx_q || (mx_s && d % 128 == 0 && (uintptr_t)mx_q % 4 == 0), "rmsnorm: the block-scaled fp8 side output needs its scale buffer and width %% 128 == 0");
+  static const bool fast256 = !(getenv("TTV_RMSNORM256") && getenv("TTV_RMSNORM256")[0] == '0');      // A/B
+  if (fast256 && rows > 0 && d == 256 && in_dtype == TTV_BF16 && out_dtype == TTV_BF16 && !src_rows && !dst_rows && !next_rstd && !mx_q && !split_image &&
+      ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gain % 16 == 0)) {
+    hipLaunchKernelGGL(k_rmsnorm256_bf16, dim3(ttv_cdiv(rows, 32)), dim3(256), 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, gain, rows, eps);
+    TTV_CHECK_LAUNCH("rmsnorm256");
+    return TTV_OK;
+  }
   if (in_dtype == TTV_F32 && out_dtype == TTV_F32) return launch_rmsnorm<float, float>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
   if (in_dtype == TTV_F32 && out_dtype == TTV_BF16) return launch_rmsnorm<float, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
   if (in_dtype == TTV_BF16 && out_dtype == TTV_BF16) return launch_rmsnorm<bf16_t, bf16_t>(in, ld_in, src_rows, out, ld_out, dst_rows, gain, rows, d, eps, s, next_rstd, mx_q, mx_s, split_image);
