@@ -1186,12 +1186,17 @@ int ttvk_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dw, int 
       int splits, tpb;
       wgrad_plan(L, N, K, &splits, &tpb);
       const int tn = ttv_cdiv(N, 128), tk = ttv_cdiv(K, 128);
-      static const bool ring_attr = [] {      // 128 KB of dynamic LDS (the 4-slot ring): above the 64 KB a launch gets without asking
-        (void)hipFuncSetAttribute((const void*)k_wgrad128_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)k_wgrad128_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE_BYTES);
-        return true;
-      }();
-      (void)ring_attr;
+      // 128 KB of dynamic LDS (the 4-slot ring): above the 64 KB a launch gets without asking - once per device of this process
+      static bool ring_attr[16] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !ring_attr[dev]) {
+        if (hipFuncSetAttribute((const void*)k_wgrad128_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad128_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_RING * WG_STAGE_BYTES) != hipSuccess) {
+          ttv_set_error("wgrad: %d bytes of dynamic LDS refused", WG_RING * WG_STAGE_BYTES);
+          return TTV_ERR_LAUNCH;
+        }
+        if (dev >= 0 && dev < 16) ring_attr[dev] = true;
+      }
 #ifdef WG_STAMPS
       { extern long long* g_ttv_stamps; long long* p__ = g_ttv_stamps; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wg_stamps_dev), &p__, sizeof(p__), 0, hipMemcpyHostToDevice, s); }
 #endif
