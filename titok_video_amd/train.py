@@ -240,6 +240,8 @@ def make_discriminator_optimizer(loss_module: torch.nn.Module, lr: float = 1e-4,
                                  beta2: float = 0.96, weight_decay: float = 1e-4):
     """AdamW over `loss_module.disc_model` at lr * disc_lr_ratio (reference train.py:195-201, configs/tiny.yaml:46)."""
     params = list(loss_module.disc_model.parameters())
+    if use_hip_adamw(params) and os.environ.get("TTV_HIP_ADAMW", "1") != "0":           # as make_optimizer
+        return HipAdamW(params, lr=lr * disc_lr_ratio, betas=(beta1, beta2), weight_decay=weight_decay)
     fused = bool(params) and all(p.is_cuda for p in params)
     return torch.optim.AdamW(params, lr=lr * disc_lr_ratio, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused)
 

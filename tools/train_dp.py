@@ -210,6 +210,9 @@ def main():
         torch.nn.utils.clip_grad_norm_ = timed(torch.nn.utils.clip_grad_norm_, "clip")
         opt_g.step = timed(opt_g.step, "opt_step")
         opt_d.step = timed(opt_d.step, "opt_step")
+        for o in (opt_g, opt_d):          # optim.HipAdamW: clip + step in one call (train.clip_and_step)
+            if hasattr(o, "clip_and_step"):
+                o.clip_and_step = timed(o.clip_and_step, "opt_step")
         real_empty = torch.empty
 
         def empty(*a, **k):           # allocations above 1 MiB (tapes, workspaces): caching-allocator misses show up here
