@@ -94,8 +94,11 @@ class ReconstructionLoss(nn.Module):
 
     # ---- discriminator step (loss_module.py:165-213) ----------------------------------------------------------------------
     def _discriminator_step_loss(self, target, recon, noise=None):
-        real = [t.detach().requires_grad_(True).contiguous() for t in target]  # as upstream (:168-169)
-        fake = [r.detach().requires_grad_(True).contiguous() for r in recon]
+        # upstream marks both lists requires_grad (:168-169) for an autograd penalty it does not take on this path: the finite-difference
+        # R1 / R2 below read logits only, so nothing reads d loss / d clip - without the flag the tower's backward skips its input
+        # gradients (patch-embed dX for every packed clip) and autograd keeps no per-clip .grad.  Loss and parameter gradients are the same.
+        real = [t.detach().contiguous() for t in target]
+        fake = [r.detach().contiguous() for r in recon]
         self._set_disc_trainable(True)
         use_penalty = self.gp_weight > 0.0
         # The reference makes 2 (+2 with the penalty) discriminator calls; clips are independent inside the tower (block-diagonal
@@ -104,8 +107,14 @@ class ReconstructionLoss(nn.Module):
         packed = real + fake
         if use_penalty:
             if noise is None:
-                noise = [torch.randn_like(t) * self.gp_noise for t in real]
-            noisy = [t + e for t, e in zip(real, noise)] + [f + e for f, e in zip(fake, noise)]
+                # one generator call for the whole batch instead of one per clip (a launch each), split into per-clip views
+                flat = torch.randn(sum(t.numel() for t in real), dtype=real[0].dtype, device=real[0].device) * self.gp_noise
+                noise, off = [], 0
+                for t in real:
+                    noise.append(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+            # multi-tensor adds: two launches instead of two per clip
+            noisy = list(torch._foreach_add(real, list(noise))) + list(torch._foreach_add(fake, list(noise)))
         if use_penalty and _TWO_CALLS:
             # two packed calls with IDENTICAL plans: clip j and its noisy copy sit at the same packed rows of their call
             scores = torch.cat([self.disc_wrapper(packed), self.disc_wrapper(noisy)]).view(-1, len(real))
