@@ -235,6 +235,7 @@ class BatchPlan:
         self._offs = offs
         self._attn = {}
         self._attn_all_full = {}
+        self._batch_structs = {}
         self.reader_streams = {}
 
     def use_on_current_stream(self) -> None:
@@ -424,7 +425,12 @@ class BatchPlan:
         return t
 
     def batch_for(self, q_heads: int, kv_heads: int) -> "_lib.Batch":
-        """ttv_batch struct whose attention work table matches the tower's head counts."""
+        """ttv_batch struct whose attention work table matches the tower's head counts (built once per head counts: every tower call of a
+        step asks for it, and a ctypes struct of ~30 fields is 40 us of host time in a step that is launch-bound at small batches)."""
+        skey = (int(q_heads), int(kv_heads)) + tuple(os.environ.get(k) for k in ("TTV_ATTN_SPLIT", "TTV_ATTN_PAIRED", "TTV_ATTN64", "TTV_ATTN_TAIL_DIV"))
+        cached = self._batch_structs.get(skey)       # (the diagnostic switches that pick the tables are part of the key)
+        if cached is not None:
+            return cached
         t = self.attention_table(q_heads, kv_heads)
         # every (sequence, kv-head) unit contributes its entries in runs of `rep` q-heads per query block, full items first:
         # with an even rep, entries 2j and 2j+1 of an XCD list are two q-heads of one kv-head on the same query rows
@@ -443,11 +449,12 @@ class BatchPlan:
         # the decoder's last layer without the query blocks that hold latent rows only (ttv_batch.qblocks_patch; TTV_DEC_PATCH_LAST=0: A/B)
         # (only beside a table of full items: the last layer must run the kernel, and the item kind, the all-blocks forward runs)
         tp = self.attention_table_patch(q_heads, kv_heads) if all_full else None
-        return _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
+        self._batch_structs[skey] = out = _lib.Batch(n_qblocks=int(t.shape[0]), qblocks=t.data_ptr(), qblocks_paired=paired, qblocks_all_full=all_full,
                           items64=t64.data_ptr() if t64 is not None else None, n_items64=int(t64.shape[0]) if t64 is not None else 0,
                           qblocks_latent=tl.data_ptr() if tl is not None else None, n_qblocks_latent=int(tl.shape[0]) if tl is not None else 0,
                           qblocks_patch=tp.data_ptr() if tp is not None else None, n_qblocks_patch=int(tp.shape[0]) if tp is not None else 0,
                           **self._base_fields)
+        return out
 
     # views used by tests that call single ops
     def table(self, i: int, n: int) -> torch.Tensor:
