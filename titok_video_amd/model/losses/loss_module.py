@@ -62,7 +62,10 @@ class ReconstructionLoss(nn.Module):
         return per_token.view(n, -1).mean(dim=-1)
 
     def _set_disc_trainable(self, flag: bool) -> None:
-        for p in self.disc_model.parameters():
+        params = self.__dict__.get("_disc_param_list")          # cached: parameters() walks the module tree, twice per step here
+        if params is None:
+            params = self.__dict__["_disc_param_list"] = list(self.disc_model.parameters())
+        for p in params:
             p.requires_grad = flag
 
     @staticmethod

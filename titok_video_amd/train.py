@@ -111,6 +111,17 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, beta1: float = 0.5,
     return torch.optim.AdamW(params, lr=lr, betas=(beta1, beta2), weight_decay=weight_decay, fused=fused, capturable=capturable and fused)
 
 
+def _param_list(module) -> list:
+    """module.parameters() as a list, cached on the module: the generator walks the module tree on every call (~0.1 ms for the tokenizer)
+    and a training step that is launch-bound at the reference's batch sizes walked it three times.  A training loop does not register
+    parameters between steps; one that does deletes module._ttv_param_list."""
+    cached = module.__dict__.get("_ttv_param_list")
+    if cached is None:
+        cached = list(module.parameters())
+        module.__dict__["_ttv_param_list"] = cached
+    return cached
+
+
 def clip_and_step(optimizer, params, max_grad_norm):
     """clip_grad_norm_(params, max_grad_norm) (skipped when max_grad_norm is falsy) + optimizer.step(); returns the gradient norm or None.
     HipAdamW does both in its own two launches (the norm is taken over the optimizer's parameters that have a gradient - the same set)."""
@@ -167,7 +178,7 @@ def training_step(model, clips: List[torch.Tensor], token_counts, optimizer, max
             red.detach(*towers)
     if red is not None:
         red.finish()                                   # joins the communication stream and delivers the towers' gradients
-    params = [p for p in model.parameters() if p.grad is not None]
+    params = [p for p in _param_list(model) if p.grad is not None]
     if red is not None:
         red.reduce_rest(params, len(clips))            # trainable parameters outside the towers (none in the reference's TiTok)
     else:
@@ -273,7 +284,7 @@ def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_count
             red.detach(*g_towers)
     if red is not None:
         red.finish()
-    g_params = [p for p in model.parameters() if p.grad is not None]
+    g_params = [p for p in _param_list(model) if p.grad is not None]
     if red is not None:
         red.reduce_rest(g_params, len(clips))
     else:
@@ -293,7 +304,7 @@ def gan_training_step(model, loss_module, clips: List[torch.Tensor], token_count
                 red.detach(*d_towers)
         if red is not None:
             red.finish()
-        d_params = [p for p in loss_module.disc_model.parameters() if p.grad is not None]
+        d_params = [p for p in _param_list(loss_module.disc_model) if p.grad is not None]
         if red is not None:
             red.reduce_rest(d_params, len(clips))
         else:
