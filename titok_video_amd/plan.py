@@ -114,6 +114,20 @@ def _rope_clip_table(grid: Tuple[int, ...], k: int, head_dim: int) -> np.ndarray
     return out
 
 
+@functools.lru_cache(maxsize=512)
+def _clip_rope_ids(grid: Tuple[int, ...], k: int, n_ids: int) -> np.ndarray:
+    """uint16 [K + P, 4] rotary position ids of one clip (rope.py:59-67): latent i -> (i, i, i), patch (t, h, w) -> (t, h, w) + K in raster
+    order, slot 3 = the identity row of the base table (pairs 30, 31).  Read-only (cached)."""
+    p = int(np.prod(grid))
+    ids = np.empty((k + p, 4), dtype=np.uint16)
+    ids[:, 3] = n_ids
+    ids[:k, :3] = np.arange(k, dtype=np.uint16)[:, None]
+    coords = np.indices(grid).reshape(len(grid), -1).T                      # raster order (t, h, w)
+    ids[k:, :3] = np.minimum(coords + k, n_ids - 1).astype(np.uint16)
+    ids.setflags(write=False)
+    return ids
+
+
 def _xcd_interleave(units) -> np.ndarray:
     """(sequence, first row) entries of the attention backward's 64-row blocks, ordered for the 8 XCDs: block b of a launch runs on XCD
     b % 8 under round-robin dispatch (a speed assumption only), and every block of a sequence streams that sequence's Q / dO (key
@@ -184,13 +198,9 @@ class BatchPlan:
         while n_ids < max(k + max(g) for g, k in zip(grids, self.token_counts)) + 1:
             n_ids *= 2
         self.n_rope_ids = n_ids
-        ids = np.empty((self.total_rows, 4), dtype=np.uint16)
-        ids[:, 3] = n_ids                                              # slot 3: the identity row of the base table (pairs 30, 31)
-        for b in range(B):
-            k = self.token_counts[b]
-            ids[cu[b]:cu[b] + k, :3] = np.arange(k, dtype=np.uint16)[:, None]
-            coords = np.indices(grids[b]).reshape(len(grids[b]), -1).T      # raster order (t, h, w)
-            ids[cu[b] + k:cu[b + 1], :3] = np.minimum(coords + k, n_ids - 1).astype(np.uint16)
+        # (per clip cached by (grid, K, table size): the loader's batches repeat a handful of clip shapes, and a step that needs three new
+        # plans at ~5 clips is bound by this host code)
+        ids = np.concatenate([_clip_rope_ids(grids[b], self.token_counts[b], n_ids) for b in range(B)], axis=0)
         rope_ids = ids.view(np.int32).reshape(-1)
         blocks64 = _xcd_interleave([[(b, r0) for r0 in range(0, cu[b + 1] - cu[b], 64)] for b in range(B)])
         row_seq = np.concatenate([np.full(cu[b + 1] - cu[b], b, dtype=np.int32) for b in range(B)])
