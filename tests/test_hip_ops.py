@@ -126,6 +126,30 @@ def test_rmsnorm(dt, d):
         assert_close(o2.float(), O.rmsnorm(xf, w), "bf16")
 
 
+@pytest.mark.parametrize("rows", [1, 7, 8, 33, 1000, 4099])
+def test_rmsnorm_width_256_bf16_fast_path(rows):
+    """k_rmsnorm256_bf16 (half a wave per row, eight rows of a wave in flight; taken for bf16 -> bf16 at width 256 without row maps): ragged
+    row counts (the last wave's rows past the end are clamped loads, no stores), leading dimensions larger than the width, against the
+    oracle and - through identity row maps, which keep the one-row-per-wave kernel - against the general kernel to one bf16 ulp."""
+    g = torch.Generator().manual_seed(rows)
+    d, ld_in, ld_out = 256, 264, 320
+    x = torch.zeros(rows, ld_in).to(torch.bfloat16)
+    x[:, :d] = (torch.randn(rows, d, generator=g) * 3).to(torch.bfloat16)
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    xd, wd = x.to(DEV), w.to(DEV)
+    out = torch.full((rows + 2, ld_out), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L().ttv_rmsnorm(xd.data_ptr(), _lib.TTV_BF16, ld_in, None, out.data_ptr(), _lib.TTV_BF16, ld_out, None, wd.data_ptr(), rows, d, 1e-5, S()),
+               "rmsnorm")
+    assert_close(out[:rows, :d].float(), O.rmsnorm(x[:, :d], w).float(), "bf16")
+    assert bool((out[rows:] == 7.0).all()) and bool((out[:, d:] == 7.0).all())          # nothing written past the rows / the width
+    ident = torch.arange(rows, dtype=torch.int32, device=DEV)
+    gen = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L().ttv_rmsnorm(xd.data_ptr(), _lib.TTV_BF16, ld_in, ident.data_ptr(), gen.data_ptr(), _lib.TTV_BF16, d, None, wd.data_ptr(), rows, d, 1e-5,
+                               S()), "rmsnorm")
+    diff = (out[:rows, :d].float() - gen.float()).abs()
+    assert float((diff / gen.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7
+
+
 # ---------------------------------------------------------------------------------------------- RoPE
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_rope_apply_matches_reference_fixture(dt):
