@@ -63,15 +63,66 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
-// ---- wave reductions (64 lanes, xor butterfly) ----------------------------------------------------
+// ---- wave reductions (64 lanes, xor butterfly 32, 16, 8, 4, 2, 1) -----------------------------------
+// Every exchange on the vector ALU: v_permlane32_swap / v_permlane16_swap for the two cross-row steps, DPP moves inside the 16-lane
+// rows (row_ror:8 = xor 8; xor 4 as two bank-masked rotations; quad_perm for xor 2 and xor 1).  __shfl_xor lowers to ds_bpermute_b32 +
+// s_waitcnt lgkmcnt(0) - an LDS round trip per step, six in a row per reduction, and the row kernels (RMSNorm forward / backward, row
+// statistics, fp8 row quantisation) are chains of such reductions.  Same partners in the same order as the butterfly above: the sums
+// are the bits they were (operands of an addition may swap sides, which changes nothing).
+__device__ __forceinline__ float wave_xor_dpp8(float v) {      // value of lane ^ 8
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x128, 0xF, 0xF, true));       // row_ror:8
+}
+__device__ __forceinline__ float wave_xor_dpp4(float v) {      // value of lane ^ 4: banks 0, 2 take lane + 4 (row_ror:12), banks 1, 3 lane - 4 (row_ror:4)
+  const int i = __builtin_bit_cast(int, v);
+  int r = __builtin_amdgcn_update_dpp(0, i, 0x12C, 0xF, 0x5, false);      // row_ror:12 -> lane i reads lane (i - 12) & 15 = (i + 4) & 15
+  r = __builtin_amdgcn_update_dpp(r, i, 0x124, 0xF, 0xA, false);          // row_ror:4  -> lane i reads lane (i - 4) & 15
+  return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float wave_xor_dpp2(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));        // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float wave_xor_dpp1(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));        // quad_perm [1,0,3,2]
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned b0 = b[0], b1 = b[1];
+    v = __uint_as_float(b0) + __uint_as_float(b1);
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    v = __uint_as_float(a0) + __uint_as_float(a1);
+  }
+  v += wave_xor_dpp8(v);
+  v += wave_xor_dpp4(v);
+  v += wave_xor_dpp2(v);
+  v += wave_xor_dpp1(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned b0 = b[0], b1 = b[1];
+    v = fmaxf(__uint_as_float(b0), __uint_as_float(b1));
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    v = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+  }
+  v = fmaxf(v, wave_xor_dpp8(v));
+  v = fmaxf(v, wave_xor_dpp4(v));
+  v = fmaxf(v, wave_xor_dpp2(v));
+  v = fmaxf(v, wave_xor_dpp1(v));
   return v;
 }
 
