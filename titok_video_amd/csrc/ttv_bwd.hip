@@ -155,9 +155,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += dpp_f(v, 1);
   v += dpp_f(v, 2);
   v += dpp_f(v, 3);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  return quad16_sum(v);        // lanes ^ 16, then ^ 32, on v_permlane16_swap / v_permlane32_swap (same association as the two ds_bpermute steps it replaces)
 }
 
 template <typename T, typename YT, int ITERS>

@@ -182,10 +182,22 @@ __global__ __launch_bounds__(256) void k_rmsnorm256_bf16(const bf16_t* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float f = (float)v[k][e]; ss[k] = fmaf(f, f, ss[k]); }
   }
+  // 32-lane sums, partners ^ 1, 2, 4, 8, 16 in that order, every exchange on the vector ALU (ttv_common.h)
 #pragma unroll
-  for (int o = 1; o < 32; o <<= 1)
+  for (int k = 0; k < 4; ++k) ss[k] += wave_xor_dpp1(ss[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ss[k] += __shfl_xor(ss[k], o, 64);
+  for (int k = 0; k < 4; ++k) ss[k] += wave_xor_dpp2(ss[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ss[k] += wave_xor_dpp4(ss[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ss[k] += wave_xor_dpp8(ss[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned u = __float_as_uint(ss[k]);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    ss[k] = __uint_as_float(a0) + __uint_as_float(a1);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + 2 * k + half;
